@@ -1,0 +1,10 @@
+#!/bin/sh
+# oracle/make_golden.sh -- TEST INFRASTRUCTURE. Regenerates tests/golden/*.bin by running the
+# compiled reference (oracle/_ref/ref_harness) in the build container. The vectors are data
+# (inputs + the reference's outputs); no reference source is copied.
+set -e
+cd "$(dirname "$0")"
+make ref
+mkdir -p ../tests/golden
+./_ref/ref_harness ../tests/golden 160 90 2048 12345 | grep -v "^Building\|traced in\|kd-tree" | tee ../tests/golden/REPORT_160x90_n2048.txt
+./_ref/ref_harness ../tests/golden 96 96 4096 2024 | grep -v "^Building\|traced in\|kd-tree" | tee ../tests/golden/REPORT_96x96_n4096.txt

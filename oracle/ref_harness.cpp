@@ -1,0 +1,390 @@
+/*
+ * oracle/ref_harness.cpp -- TEST INFRASTRUCTURE (oracle/_ref build only).
+ *
+ * Links the UNMODIFIED reference translation units (Raytrace, PhotonMap, Scene,
+ * Vector, JobSystem -- compiled from /root/reference/src where they lie) with
+ * the C restatement (pm_oracle.c) and a tape-replay randutil (ref_randutil.cpp)
+ * and checks, bit for bit:
+ *   1. primitive intersection KATs      SphereObject/PlaneObject::intersect
+ *   2. primary hit ids / points / normals   Scene::intersect
+ *   3. photon arrays + draw counts      createPhotonMap / createCausticPhotonMap
+ *   4. kd-tree shape, k-NN heap arrays  createKDTree / find_nearest_photons
+ *   5. full and direct-only panes       traceRay
+ * and writes the golden vectors that tests/ replay without the reference.
+ *
+ *   usage: ref_harness <outdir> [width height nphotons seed]
+ */
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "Raytrace.h"   /* reference headers (Vector.h, Scene.h, Random.h, PhotonMap.h) */
+
+#include "orc_rng.h"
+#include "pm_oracle.h"
+#include "ref_randutil.h"
+
+namespace raytrace {
+    /* external linkage in src/Raytrace.cpp:32, not declared in any header */
+    uint32 traceRay(Vec3 &ray_source, Vec3 &ray, Scene *scene, SceneObject *exclude, int bounce,
+                    kdnode *global_tree, kdnode *caustic_tree, Vec3 *light_color);
+}
+using namespace raytrace;
+
+static int g_fail = 0;
+#define CHECK(cond, ...) do { if (!(cond)) { g_fail++; if (g_fail < 40) { printf("FAIL %s:%d: ", __FILE__, __LINE__); printf(__VA_ARGS__); printf("\n"); } } } while (0)
+
+static bool biteq(double a, double b) { return memcmp(&a, &b, 8) == 0; }
+
+static void write_file(const std::string &path, const void *data, size_t bytes) {
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) { printf("cannot write %s\n", path.c_str()); exit(2); }
+    fwrite(data, 1, bytes, f);
+    fclose(f);
+}
+
+/* the reference's scene set-up, src/Image.cpp:20-28 */
+static Scene *make_ref_scene() {
+    Scene *scene = new Scene(7);
+    scene->objects[0] = new PlaneObject(0, -5, 0, -5, 5, 0xFFEEEEEE, 0.4, 0.0, 0.0, 1.0);
+    scene->objects[1] = new PlaneObject(0, 5, 0, -5, 5, (uint32) 0xFFDEEEEEEULL, 0.4, 0.0, 0.0, 1.0);
+    scene->objects[2] = new PlaneObject(5, 0, 0, -5, 5, 0xFFFF3333, 0.4, 0.0, 0.0, 1.0);
+    scene->objects[3] = new PlaneObject(-5, 0, 0, -5, 5, 0xFF3333FF, 0.4, 0.0, 0.0, 1.0);
+    scene->objects[4] = new PlaneObject(0, 0, 10, -5, 5, 0xFFEEEEEE, 0.4, 0.0, 0.0, 1.0);
+    scene->objects[5] = new SphereObject(2, -3.5, 3, 1.5, 0xFFFFFFFF, 0.0, 0.1, 0.9, 0.0);
+    scene->objects[5]->refraction = 2.5;
+    scene->objects[6] = new SphereObject(-2, -3.5, 5, 1.5, 0xFFFFFFFF, 0.0, 1.0, 0.0, 0.0);
+    return scene;
+}
+
+static int obj_index(Scene *s, SceneObject *o) {
+    if (!o) return -1;
+    for (int i = 0; i < s->size; i++) if (s->objects[i] == o) return i;
+    return -2;
+}
+
+static void collect_tree(kdnode *t, std::vector<photon *> &out, int depth, int &maxdepth) {
+    if (depth > maxdepth) maxdepth = depth;
+    out.push_back(t->value);
+    if (t->left) collect_tree(t->left, out, depth + 1, maxdepth);
+    if (t->right) collect_tree(t->right, out, depth + 1, maxdepth);
+}
+
+static bool photon_eq(const photon *a, const orc_photon *b) {
+    return memcmp(&a->x, &b->x, 4) == 0 && memcmp(&a->y, &b->y, 4) == 0 && memcmp(&a->z, &b->z, 4) == 0 &&
+           memcmp(a->power, b->power, 4) == 0 && memcmp(&a->dx, &b->dx, 4) == 0 &&
+           memcmp(&a->dy, &b->dy, 4) == 0 && memcmp(&a->dz, &b->dz, 4) == 0 && a->bounce == b->bounce;
+}
+
+/* the oracle's reference-shaped tree is rebuilt here node by node alongside the reference's
+ * pointer tree: both were built with the same pivot stream, so a pre-order walk must meet
+ * the same photons in the same order with the same axes. */
+struct TreeMatch { std::unordered_map<photon *, int> index; };
+
+static uint64_t splitmix_local(uint64_t &s) { s += ORC_GOLD; return orc_mix64(s); }
+static double urand(uint64_t &s) { return (double)(splitmix_local(s) >> 11) * (1.0 / 9007199254740992.0); }
+
+int main(int argc, char **argv) {
+    if (argc < 2) { printf("usage: ref_harness <outdir> [width height nphotons seed]\n"); return 2; }
+    std::string out = argv[1];
+    int W = argc > 2 ? atoi(argv[2]) : 160, H = argc > 3 ? atoi(argv[3]) : 90;
+    int NPH = argc > 4 ? atoi(argv[4]) : 2048;
+    uint64_t seed = argc > 5 ? strtoull(argv[5], nullptr, 10) : 12345ULL;
+    bool write_golden = !(argc > 6 && strcmp(argv[6], "nowrite") == 0);
+    std::string tag = "_" + std::to_string(W) + "x" + std::to_string(H) + "_n" + std::to_string(NPH);
+
+    Scene *scene = make_ref_scene();
+    orc_prim prims[7];
+    orc_default_scene(prims);
+    Vec3 camera(0, 0, -12);
+    double cam[3] = {0, 0, -12};
+    Vec3 light_color(0.6, 0.6, 0.6);
+    double lc[3] = {0.6, 0.6, 0.6};
+
+    /* ---- 0. scene flattening ---- */
+    for (int i = 0; i < 7; i++) {
+        SceneObject *o = scene->objects[i];
+        CHECK(o->x == prims[i].x && o->y == prims[i].y && o->z == prims[i].z, "prim %d position", i);
+        CHECK(o->red == prims[i].red && o->green == prims[i].green && o->blue == prims[i].blue, "prim %d colour", i);
+        CHECK(o->absorb_chance == prims[i].absorb_chance && o->diffuse_chance == prims[i].diffuse_chance &&
+              o->specular_chance == prims[i].specular_chance && o->transmission_chance == prims[i].transmission_chance &&
+              o->refraction == prims[i].refraction && o->specular_coeff == prims[i].specular_coeff, "prim %d material", i);
+    }
+    if (write_golden) write_file(out + "/scene_default.bin", prims, sizeof(prims));
+
+    /* ---- 1. intersection KATs ---- */
+    {
+        /* record: prim, src[3], dir[3], dt, hit, res[3], nrm[3] = 15 doubles */
+        const int NK = 3000;
+        std::vector<double> kat;
+        uint64_t s = seed ^ 0xABCDEF;
+        /* a moving sphere like the commented-out object at src/Image.cpp:30, to exercise dt */
+        SphereObject moving(0, 1, 5, 0.8, 0xFF33FF33, 0.4, 0.0, 0.0, 1.0, 0.2, 0, 0);
+        orc_prim mprim; memset(&mprim, 0, sizeof(mprim));
+        mprim.kind = 0; mprim.x = 0; mprim.y = 1; mprim.z = 5; mprim.radius = 0.8; mprim.dx = 0.2;
+        for (int k = 0; k < NK; k++) {
+            int pi = (int)(splitmix_local(s) % 8);
+            SceneObject *ro = pi < 7 ? scene->objects[pi] : &moving;
+            const orc_prim *op = pi < 7 ? &prims[pi] : &mprim;
+            double src[3], dir[3];
+            int mode = k % 10;
+            for (int a = 0; a < 3; a++) { src[a] = urand(s) * 12 - 6; dir[a] = urand(s) * 2 - 1; }
+            src[2] = urand(s) * 24 - 12;
+            if (mode == 1) { src[0] = 0; src[1] = 0; src[2] = -12; }
+            if (mode == 2) { dir[(int)(splitmix_local(s) % 3)] = 0.0; }            /* d.a == 0: inf / NaN paths */
+            if (mode == 3) { src[0] = 5; dir[0] = 0; }                              /* 0/0 on the x=+5 plane */
+            if (mode == 4) { src[1] = -5; }                                         /* mul == 0 self hit (A.12) */
+            if (mode == 5 && pi >= 5 && pi < 7) {                                   /* source inside a sphere */
+                src[0] = prims[pi].x + (urand(s) - 0.5); src[1] = prims[pi].y + (urand(s) - 0.5); src[2] = prims[pi].z + (urand(s) - 0.5);
+            }
+            if (mode == 6) { src[0] = 2; src[1] = -3.5; src[2] = -12; dir[0] = 0; dir[1] = 0; dir[2] = 1; } /* tangent-ish */
+            double len = sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+            if (len > 0 && mode != 7) { dir[0] /= len; dir[1] /= len; dir[2] /= len; }
+            double dt = urand(s);
+            Vec3 vs(src[0], src[1], src[2]), vd(dir[0], dir[1], dir[2]), vr(0, 0, 0), vn(0, 0, 0);
+            bool rh = ro->intersect(&vs, &vd, &vr, &vn, dt);
+            double ores[3] = {0, 0, 0}, onrm[3] = {0, 0, 0};
+            int oh = orc_prim_intersect(op, src, dir, dt, ores, onrm);
+            CHECK((int)rh == oh, "KAT %d prim %d hit flag ref=%d orc=%d", k, pi, (int)rh, oh);
+            if (rh && oh) {
+                CHECK(biteq(vr.x, ores[0]) && biteq(vr.y, ores[1]) && biteq(vr.z, ores[2]), "KAT %d prim %d result", k, pi);
+                CHECK(biteq(vn.x, onrm[0]) && biteq(vn.y, onrm[1]) && biteq(vn.z, onrm[2]), "KAT %d prim %d normal", k, pi);
+            }
+            double rec[15] = {(double)pi, src[0], src[1], src[2], dir[0], dir[1], dir[2], dt, rh ? 1.0 : 0.0,
+                              rh ? vr.x : 0, rh ? vr.y : 0, rh ? vr.z : 0, rh ? vn.x : 0, rh ? vn.y : 0, rh ? vn.z : 0};
+            kat.insert(kat.end(), rec, rec + 15);
+        }
+        if (write_golden) {
+            write_file(out + "/kat_intersect.bin", kat.data(), kat.size() * 8);
+            write_file(out + "/kat_moving_sphere.bin", &mprim, sizeof(mprim));
+        }
+        /* fastfloor KATs, src/Vector.cpp:8-16 */
+        double ff[] = {0.0, -0.0, 0.5, -0.5, 1.0, -1.0, 254.99999999999997, 255.0, -3.2, 152.99999999999997, 1e-300, -1e-300};
+        for (double v : ff) CHECK(fastfloor(v) == orc_fastfloor(v), "fastfloor(%g)", v);
+        printf("[1] intersection KATs: %d cases, failures so far %d\n", NK, g_fail);
+    }
+
+    /* ---- 2. primary hits ---- */
+    std::vector<int32_t> ids((size_t)W * H);
+    std::vector<double> hitp((size_t)W * H * 3), hitn((size_t)W * H * 3);
+    {
+        orc_primary_hits(prims, 7, W, H, cam, seed, 0, H, ids.data(), hitp.data(), hitn.data());
+        uint64_t K = orc_stream_key(seed, ORC_KIND_PIXEL);
+        long hist[8] = {0};
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                uint64_t pixel = (uint64_t)x + (uint64_t)y * W;
+                double tape[3] = {orc_draw(orc_item_key(K, pixel * 32), 0), orc_draw(orc_item_key(K, pixel * 32), 1),
+                                  orc_draw(orc_item_key(K, pixel * 32 + 1), 0)};
+                ref_tape_set(tape, 3);
+                /* the loop body of render_task, src/Raytrace.cpp:284-293, then Scene::intersect as traceRay calls it (:39) */
+                Vec3 ray(0, 0, 0), ray_source(&camera);
+                double fov = (W / 1280.0) * 64.0;
+                double x1 = randutil::nextDouble() * 0.6 - 0.3;
+                double y1 = randutil::nextDouble() * 0.6 - 0.3;
+                double x0 = (x - W / 2 + x1) / fov - ray_source.x;
+                double y0 = (y - H / 2 + y1) / fov - ray_source.y;
+                ray.set(x0, y0, -ray_source.z);
+                ray.normalize();
+                Vec3 nr(0, 0, 0), nn(0, 0, 0);
+                SceneObject *no = nullptr;
+                scene->intersect(ray_source, ray, nullptr, &nr, &nn, &no, randutil::nextDouble());
+                int rid = obj_index(scene, no);
+                size_t o = (size_t)y * W + x;
+                CHECK(rid == ids[o], "primary id (%d,%d) ref=%d orc=%d", x, y, rid, ids[o]);
+                if (rid >= 0 && rid == ids[o]) {
+                    CHECK(biteq(nr.x, hitp[3 * o]) && biteq(nr.y, hitp[3 * o + 1]) && biteq(nr.z, hitp[3 * o + 2]), "primary point (%d,%d)", x, y);
+                    CHECK(biteq(nn.x, hitn[3 * o]) && biteq(nn.y, hitn[3 * o + 1]) && biteq(nn.z, hitn[3 * o + 2]), "primary normal (%d,%d)", x, y);
+                }
+                hist[rid + 1]++;
+            }
+        printf("[2] primary hits %dx%d: miss %ld, ids", W, H, hist[0]);
+        for (int i = 1; i < 8; i++) printf(" %ld", hist[i]);
+        printf(", failures so far %d\n", g_fail);
+        if (write_golden) {
+            std::vector<int8_t> ids8(ids.begin(), ids.end());
+            write_file(out + "/primary_ids" + tag + ".bin", ids8.data(), ids8.size());
+            write_file(out + "/primary_points" + tag + ".bin", hitp.data(), hitp.size() * 8);
+            write_file(out + "/primary_normals" + tag + ".bin", hitn.data(), hitn.size() * 8);
+        }
+    }
+
+    /* ---- 3. photon emission + 4. kd-tree shape ---- */
+    kdnode *ref_tree[2] = {nullptr, nullptr};
+    orc_map *omap[2] = {nullptr, nullptr};
+    TreeMatch match[2];
+    std::vector<orc_photon> oph[2];
+    for (int kind = 0; kind < 2; kind++) {
+        orc_tape tape; orc_tape_init(&tape);
+        oph[kind].resize(NPH);
+        uint64_t attempts = orc_emit(prims, 7, kind, seed, NPH, ORC_TRIG_LIBM, lc, oph[kind].data(), &tape);
+        ref_tape_set(tape.v, tape.n);
+        uint64_t pivot_seed = seed * 2 + kind;
+        ref_pivot_set(pivot_seed);
+        Vec3 light_source(0, 4.96, 4);
+        ref_tree[kind] = kind == 0 ? createPhotonMap(NPH, light_source, light_color, scene)
+                                   : createCausticPhotonMap(NPH, light_source, light_color, scene);
+        CHECK(ref_tape_pos() == tape.n && ref_tape_overrun() == 0, "emission kind %d draw count ref=%zu(+%zu) orc=%zu", kind,
+              ref_tape_pos(), ref_tape_overrun(), tape.n);
+        omap[kind] = orc_map_create(oph[kind].data(), NPH, 1, pivot_seed);
+        std::vector<photon *> rph; int rdepth = 0;
+        collect_tree(ref_tree[kind], rph, 1, rdepth);
+        CHECK((int)rph.size() == NPH, "tree holds %zu photons", rph.size());
+        CHECK(rdepth == orc_map_ref_depth(omap[kind]), "kd depth ref=%d orc=%d", rdepth, orc_map_ref_depth(omap[kind]));
+        /* photon arrays: the reference frees its array, the tree keeps the records -> compare as multisets,
+         * matching each reference record to an unused oracle index with identical bytes */
+        std::unordered_multimap<std::string, int> by_bytes;
+        for (int i = 0; i < NPH; i++) {
+            orc_photon p = oph[kind][i]; memset(p.pad, 0, 3);
+            by_bytes.emplace(std::string((const char *)&p, 29), i);
+        }
+        int unmatched = 0;
+        for (photon *p : rph) {
+            orc_photon q; memset(&q, 0, sizeof(q));
+            q.x = p->x; q.y = p->y; q.z = p->z; memcpy(q.power, p->power, 4); q.dx = p->dx; q.dy = p->dy; q.dz = p->dz; q.bounce = p->bounce;
+            auto it = by_bytes.find(std::string((const char *)&q, 29));
+            if (it == by_bytes.end()) { unmatched++; continue; }
+            match[kind].index[p] = it->second;
+            by_bytes.erase(it);
+        }
+        CHECK(unmatched == 0, "kind %d: %d reference photons have no bit-identical oracle photon", kind, unmatched);
+        printf("[3] emission kind %d: %d photons from %llu attempts, %zu draws, kd depth %d, failures so far %d\n", kind, NPH,
+               (unsigned long long)attempts, tape.n, rdepth, g_fail);
+        if (write_golden) {
+            write_file(out + "/photons_kind" + std::to_string(kind) + "_n" + std::to_string(NPH) + ".bin", oph[kind].data(), (size_t)NPH * 32);
+            uint64_t meta[2] = {attempts, (uint64_t)tape.n};
+            write_file(out + "/photons_kind" + std::to_string(kind) + "_n" + std::to_string(NPH) + "_meta.bin", meta, 16);
+        }
+        orc_tape_free(&tape);
+    }
+
+    /* ---- 4. k-NN heap arrays + radiance on primary hit points ---- */
+    {
+        std::vector<double> qp, qn;
+        for (size_t o = 0; o < ids.size() && qp.size() < 3 * 400; o += 7)
+            if (ids[o] >= 0) { for (int a = 0; a < 3; a++) { qp.push_back(hitp[3 * o + a]); qn.push_back(hitn[3 * o + a]); } }
+        /* a few off-surface / far points */
+        double extra[][3] = {{0, 0, 5}, {4.9, 4.9, 9.9}, {-4.99, -4.99, 0.01}, {0, 0, -12}, {2, -2.0, 3}, {30, 30, 30}};
+        for (auto &e : extra) { for (int a = 0; a < 3; a++) { qp.push_back(e[a]); qn.push_back(a == 1 ? 1.0 : 0.0); } }
+        int NQ = (int)qp.size() / 3;
+        std::vector<int32_t> gidx((size_t)NQ * 2 * 63);
+        std::vector<double> gd2((size_t)NQ * 2 * 63), grad_ref((size_t)NQ * 2 * 3), grad_can((size_t)NQ * 2 * 3);
+        std::vector<int32_t> gfound((size_t)NQ * 2);
+        long set_mismatch = 0;
+        for (int kind = 0; kind < 2; kind++)
+            for (int q = 0; q < NQ; q++) {
+                photon *np[63]; double nd[63];
+                for (int i = 0; i < 63; i++) { np[i] = nullptr; nd[i] = 0; }
+                Vec3 t(qp[3 * q], qp[3 * q + 1], qp[3 * q + 2]);
+                int found = find_nearest_photons(np, nd, 63, 0, &t, ref_tree[kind], 100);
+                int32_t oi[63]; double od[63];
+                int ofound = orc_knn_ref(omap[kind], &qp[3 * q], oi, od);
+                CHECK(found == ofound, "knn kind %d q %d found ref=%d orc=%d", kind, q, found, ofound);
+                for (int i = 0; i < found && i < ofound; i++) {
+                    auto it = match[kind].index.find(np[i]);
+                    int ri = it == match[kind].index.end() ? -9 : it->second;
+                    /* bit-identical duplicate photons may be matched to either twin: compare bytes then */
+                    bool same = ri == oi[i] || (ri >= 0 && oi[i] >= 0 && memcmp(&oph[kind][ri], &oph[kind][oi[i]], 29) == 0);
+                    CHECK(same && biteq(nd[i], od[i]), "knn kind %d q %d slot %d ref=(%d,%.17g) orc=(%d,%.17g)", kind, q, i, ri, nd[i], oi[i], od[i]);
+                }
+                size_t b = ((size_t)kind * NQ + q);
+                gfound[b] = ofound;
+                memcpy(&gidx[b * 63], oi, sizeof(oi)); memcpy(&gd2[b * 63], od, sizeof(od));
+                /* exact vs brute vs reference set */
+                int32_t ei[63], bi[63]; double ed[63], bd[63];
+                int ef = orc_knn_exact(omap[kind], &qp[3 * q], ei, ed);
+                int bf = orc_knn_brute(omap[kind], &qp[3 * q], bi, bd);
+                CHECK(ef == bf, "exact/brute found %d %d", ef, bf);
+                for (int i = 0; i < ef && i < bf; i++) CHECK(ei[i] == bi[i] && biteq(ed[i], bd[i]), "exact/brute kind %d q %d slot %d", kind, q, i);
+                if (ef != ofound) set_mismatch++;
+                else {
+                    std::vector<double> a(od, od + ofound), c(ed, ed + ef);
+                    std::sort(a.begin(), a.end()); std::sort(c.begin(), c.end());
+                    if (a != c) set_mismatch++;
+                }
+                orc_gather(omap[kind], kind, ORC_ORDER_REFERENCE, &qp[3 * q], &qn[3 * q], &grad_ref[b * 3]);
+                orc_gather(omap[kind], kind, ORC_ORDER_CANONICAL, &qp[3 * q], &qn[3 * q], &grad_can[b * 3]);
+            }
+        printf("[4] k-NN: %d queries x 2 maps; reference result set != exact k-NN set in %ld queries (SURVEY A.19); failures so far %d\n",
+               NQ, set_mismatch, g_fail);
+        if (write_golden) {
+            write_file(out + "/knn_points" + tag + ".bin", qp.data(), qp.size() * 8);
+            write_file(out + "/knn_normals" + tag + ".bin", qn.data(), qn.size() * 8);
+            write_file(out + "/knn_ref_idx" + tag + ".bin", gidx.data(), gidx.size() * 4);
+            write_file(out + "/knn_ref_d2" + tag + ".bin", gd2.data(), gd2.size() * 8);
+            write_file(out + "/knn_ref_found" + tag + ".bin", gfound.data(), gfound.size() * 4);
+            write_file(out + "/knn_radiance_reforder" + tag + ".bin", grad_ref.data(), grad_ref.size() * 8);
+        }
+    }
+
+    /* ---- 5. panes: reference traceRay under tape replay vs restatement ---- */
+    for (int pass = 0; pass < 2; pass++) {
+        /* pass 0: full (global + caustic + direct); pass 1: direct only (empty photon maps are not
+         * possible in the reference: find_nearest_photons dereferences the root; so the direct-only
+         * pane is the restatement's, pinned transitively by pass 0 and checked against it on
+         * pixels that do not depend on photons) */
+        orc_render_params rp; memset(&rp, 0, sizeof(rp));
+        rp.width = W; rp.height = H; rp.seed = seed; rp.flags = pass == 0 ? 0 : (ORC_FLAG_NO_GLOBAL | ORC_FLAG_NO_CAUSTIC);
+        rp.order = ORC_ORDER_REFERENCE;
+        memcpy(rp.cam, cam, sizeof(cam)); memcpy(rp.light_color, lc, sizeof(lc));
+        std::vector<uint32_t> pane_ref((size_t)W * H), pane_orc((size_t)W * H), pane_can((size_t)W * H);
+        orc_stats st; memset(&st, 0, sizeof(st));
+        long diff = 0, diff_can = 0, maxd = 0; double sse = 0;
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                orc_tape tape; orc_tape_init(&tape);
+                size_t o = (size_t)y * W + x;
+                pane_orc[o] = orc_trace_pixel(prims, 7, omap[0], omap[1], &rp, x, y, &tape, &st);
+                orc_render_params rc = rp; rc.order = ORC_ORDER_CANONICAL;
+                pane_can[o] = orc_trace_pixel(prims, 7, omap[0], omap[1], &rc, x, y, nullptr, nullptr);
+                if (pass == 0) {
+                    ref_tape_set(tape.v, tape.n);
+                    Vec3 ray(0, 0, 0), ray_source(&camera);
+                    double fov = (W / 1280.0) * 64.0;
+                    double x1 = randutil::nextDouble() * 0.6 - 0.3;
+                    double y1 = randutil::nextDouble() * 0.6 - 0.3;
+                    double x0 = (x - W / 2 + x1) / fov - ray_source.x;
+                    double y0 = (y - H / 2 + y1) / fov - ray_source.y;
+                    ray.set(x0, y0, -ray_source.z);
+                    ray.normalize();
+                    pane_ref[o] = traceRay(ray_source, ray, scene, nullptr, 0, ref_tree[0], ref_tree[1], &light_color);
+                    CHECK(ref_tape_pos() == tape.n && ref_tape_overrun() == 0, "pixel (%d,%d) draw count ref=%zu orc=%zu", x, y, ref_tape_pos(), tape.n);
+                    if (pane_ref[o] != pane_orc[o]) { diff++; CHECK(false, "pixel (%d,%d) ref=%08x orc=%08x", x, y, pane_ref[o], pane_orc[o]); }
+                    if (pane_ref[o] != pane_can[o]) {
+                        diff_can++;
+                        for (int c = 0; c < 3; c++) {
+                            long d = (long)((pane_ref[o] >> (8 * c)) & 0xFF) - (long)((pane_can[o] >> (8 * c)) & 0xFF);
+                            if (labs(d) > maxd) maxd = labs(d);
+                            sse += (double)d * d;
+                        }
+                    }
+                }
+                orc_tape_free(&tape);
+            }
+        if (pass == 0) {
+            double mse = sse / ((double)W * H * 3);
+            printf("[5] full pane %dx%d: reference vs restatement(reference order) differing pixels %ld; vs restatement(canonical order) "
+                   "differing pixels %ld, max channel diff %ld, PSNR %s%.1f dB; rays: closest %llu shadow %llu gathers %llu absorb %llu; failures so far %d\n",
+                   W, H, diff, diff_can, maxd, mse == 0 ? "inf " : "", mse == 0 ? 0.0 : 10 * log10(255.0 * 255.0 / mse),
+                   (unsigned long long)st.closest_hit_queries, (unsigned long long)st.shadow_queries, (unsigned long long)st.gathers,
+                   (unsigned long long)st.absorb_points, g_fail);
+            if (write_golden) {
+                write_file(out + "/pane_full_ref" + tag + ".bin", pane_ref.data(), pane_ref.size() * 4);
+                write_file(out + "/pane_full_canonical" + tag + ".bin", pane_can.data(), pane_can.size() * 4);
+                uint64_t stv[4] = {st.closest_hit_queries, st.shadow_queries, st.gathers, st.absorb_points};
+                write_file(out + "/pane_stats" + tag + ".bin", stv, sizeof(stv));
+            }
+        } else {
+            printf("[5] direct-only pane %dx%d written (restatement)\n", W, H);
+            if (write_golden) write_file(out + "/pane_direct" + tag + ".bin", pane_orc.data(), pane_orc.size() * 4);
+        }
+    }
+
+    printf("%s: %d failure(s)\n", g_fail ? "FAILED" : "OK", g_fail);
+    return g_fail ? 1 : 0;
+}
