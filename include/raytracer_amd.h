@@ -1,0 +1,147 @@
+/*
+ * raytracer_amd.h -- C-ABI of libraytracer_amd.so (MI355X / gfx950 HIP backend).
+ *
+ * The reference (Deamon5550/raytracer) has no FFI; its seam is the JobSystem worker pool
+ * (src/JobSystem.h:5-19) plus the C++ functions the jobs call.  This library replaces the CPU
+ * workers for the hot path only: per-pixel trace / intersect / shade (src/Raytrace.cpp:32-299)
+ * and photon emission + k-NN radiance gather (src/PhotonMap.cpp).  Each entry point names the
+ * reference interface it stands in for.  All functions return 0 on success, a negative PM_E*
+ * code otherwise (the reference has no error channel: every function there returns void);
+ * pm_last_error() gives the message.  One context per process and GPU; calls on one context
+ * must come from one host thread at a time.  All work is issued on the context's stream
+ * (default: the null stream, so it orders with PyTorch-ROCm's default stream).
+ *
+ * Random numbers follow "RNG contract v1" (DESIGN.md): counter-based streams keyed by
+ * (seed, kind, item, draw#) that replace the reference's single racy global engine
+ * (src/Random.cpp:8-27).
+ */
+#ifndef RAYTRACER_AMD_H
+#define RAYTRACER_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PM_OK 0
+#define PM_EINVAL (-1)   /* bad argument */
+#define PM_EHIP (-2)     /* HIP runtime error */
+#define PM_ENOMEM (-3)
+#define PM_ESTATE (-4)   /* e.g. no scene uploaded */
+
+/* Flattened SceneObject / SphereObject / PlaneObject (src/Scene.h:8-59); array index = hit id. */
+typedef struct pm_prim {
+    int32_t kind;               /* 0 = SphereObject, 1 = PlaneObject */
+    int32_t pad0;
+    double x, y, z;             /* SceneObject::x,y,z (plane: exactly one non-zero selects the axis) */
+    double radius;              /* SphereObject::radius */
+    double dx, dy, dz;          /* SphereObject::dx,dy,dz */
+    double min_bound, max_bound;/* PlaneObject::min_bound,max_bound */
+    float red, green, blue;     /* colour byte / 255.0f (src/Scene.cpp:54-56) */
+    float pad1;
+    double absorb_chance, diffuse_chance, specular_chance, transmission_chance;
+    double refraction, specular_coeff;
+} pm_prim;                      /* 144 bytes */
+
+/* struct photon, src/PhotonMap.h:8-13 (32 bytes, same field order). */
+typedef struct pm_photon {
+    float x, y, z;
+    uint8_t power[4];
+    float dx, dy, dz;
+    int8_t bounce;
+    uint8_t pad[3];
+} pm_photon;
+
+typedef struct pm_ctx pm_ctx;   /* replaces the scheduler's global state, src/JobSystem.cpp:29-35 */
+typedef struct pm_map pm_map;   /* replaces kdnode* (src/PhotonMap.h:15-20) */
+
+#define PM_MAP_GLOBAL 0         /* createPhotonMap */
+#define PM_MAP_CAUSTIC 1        /* createCausticPhotonMap */
+
+#define PM_FLAG_NO_GLOBAL 1     /* skip the global-map gather (src/Raytrace.cpp:96-131) */
+#define PM_FLAG_NO_CAUSTIC 2    /* skip the caustic-map gather (:135-171) */
+#define PM_FLAG_NO_DIRECT 4     /* zero the shadow-ray direct term (:174-212) */
+
+#define PM_K 63                 /* PHOTONS_IN_ESTIMATE, src/Raytrace.cpp:16,21 (heap only defined for 63, PhotonMap.cpp:174) */
+#define PM_ROW_BLOCK 16         /* rows per interleaved row block when a frame is split over ranks */
+
+typedef struct pm_render_params {
+    int32_t width, height;      /* pane size (any W x H; the 16:9 rule lives in Main.cpp only) */
+    double cam[3];              /* camera, src/Image.cpp:33 */
+    double light_color[3];      /* src/Raytrace.cpp:311 */
+    uint64_t seed;
+    int32_t flags;              /* PM_FLAG_* */
+    int32_t rank, world;        /* this call renders row blocks b with b % world == rank (rows 16b..16b+15) */
+    int32_t reserved;
+} pm_render_params;
+
+typedef struct pm_stats {
+    uint64_t closest_hit_queries;  /* Scene::intersect calls made by traceRay */
+    uint64_t shadow_queries;       /* shadow any-hit queries (25 per absorb point) */
+    uint64_t gathers;              /* find_nearest_photons top-level calls */
+    uint64_t absorb_points;
+    uint64_t complex_pixels;       /* pixels whose primary hit reflects or refracts */
+    /* device time of each phase of the last call, from HIP events on the context's stream (ms) */
+    float ms_primary, ms_secondary, ms_shadow, ms_gather_global, ms_gather_caustic, ms_resolve, ms_total;
+    float pad;
+} pm_stats;
+
+/* scheduler::startWorkers(int), src/JobSystem.cpp:76-86 (called at src/Main.cpp:34): `device` takes the place of `cores`. */
+int pm_ctx_create(int device, pm_ctx **out);
+int pm_ctx_destroy(pm_ctx *ctx);
+/* Issue all work on this hipStream_t (NULL = the null stream). */
+int pm_ctx_set_stream(pm_ctx *ctx, void *hip_stream);
+const char *pm_last_error(void);
+
+/* Scene + SceneObject*[] (src/Scene.h:24-34): flattened copy, index = object id. */
+int pm_scene_upload(pm_ctx *ctx, const pm_prim *prims, int32_t n);
+
+/* The outer while-loop body of createPhotonMap / createCausticPhotonMap (src/PhotonMap.cpp:288-367,
+ * 400-484) for emission attempts [attempt_begin, attempt_begin + attempt_count), one attempt per
+ * lane, compacted in attempt order.  d_out is DEVICE memory for `cap` records; *out_count receives
+ * the number of successful attempts in the range (may exceed cap; only the first cap are written). */
+int pm_emit_range(pm_ctx *ctx, int32_t map_kind, uint64_t seed, const double light_color[3],
+                  uint64_t attempt_begin, uint64_t attempt_count, pm_photon *d_out, uint64_t cap,
+                  uint64_t *out_count);
+
+/* createKDTree (src/PhotonMap.cpp:64-140): builds the spatial index (64-ary BVH over Morton-sorted
+ * photons) from n records in emission order.  records_on_device: 0 = host pointer, 1 = device. */
+int pm_map_build(pm_ctx *ctx, const pm_photon *records, int64_t n, int32_t records_on_device, pm_map **out);
+
+/* createPhotonMap / createCausticPhotonMap (src/PhotonMap.h:28-29): the first n successful attempts,
+ * in attempt order from attempt 0, then pm_map_build.  *attempts_used may be NULL. */
+int pm_map_create(pm_ctx *ctx, int32_t map_kind, int64_t n, uint64_t seed, const double light_color[3],
+                  pm_map **out, uint64_t *attempts_used);
+int pm_map_size(const pm_map *map, int64_t *n);
+/* Copies the n records, in emission order, to host memory. */
+int pm_map_download(pm_map *map, pm_photon *host_out);
+/* deleteTree, src/PhotonMap.cpp:504-513 */
+int pm_map_destroy(pm_map *map);
+
+/* find_nearest_photons (src/PhotonMap.cpp:210-255) with k = 63, max_dist = 100 for m query points
+ * (host arrays; points m x 3 doubles).  Per query: found (<= 63), then idx / d2 ascending by
+ * (d2, emission index); unused slots are -1 / 0. */
+int pm_knn_query(pm_ctx *ctx, pm_map *map, int64_t m, const double *points, int32_t *idx, double *d2,
+                 int32_t *found);
+
+/* find_nearest_photons + the radiance loop of src/Raytrace.cpp:97-131 (map_kind GLOBAL) or :136-170
+ * (CAUSTIC) for m points; radiance is m x 3 doubles.  on_device: 0 = host arrays, 1 = device arrays. */
+int pm_knn_gather(pm_ctx *ctx, pm_map *map, int32_t map_kind, int64_t m, const double *points,
+                  const double *normals, double *radiance, int32_t on_device);
+
+/* render_task up to the first Scene::intersect (src/Raytrace.cpp:284-293,:39): hit ids (-1 = miss),
+ * hit points and normals (NULL to skip) for rows y0 <= y < y1; host arrays, (y1-y0) x width entries. */
+int pm_primary_hits(pm_ctx *ctx, const pm_render_params *rp, int32_t y0, int32_t y1, int32_t *ids,
+                    double *points, double *normals);
+
+/* The submit loop + waitForCompletion of renderScene (src/Raytrace.cpp:322-336): traces this rank's
+ * row blocks into `pane` (full width x height image, pane[x + y*width] = 0xAARRGGBB; rows of other
+ * ranks are left untouched).  pane_on_device: 0 = host, 1 = device.  gmap / cmap may be NULL only
+ * with the matching PM_FLAG_NO_* flag.  stats may be NULL. */
+int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_params *rp, uint32_t *pane,
+              int32_t pane_on_device, pm_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

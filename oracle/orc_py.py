@@ -1,0 +1,166 @@
+"""oracle/orc_py.py -- TEST INFRASTRUCTURE: ctypes loader for the C restatement (oracle/pm_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.  The
+product package (raytracer_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "_build", "liboracle.so")
+
+ORDER_CANONICAL, ORDER_REFERENCE = 0, 1
+TRIG_LIBM, TRIG_DET = 0, 1
+MAP_GLOBAL, MAP_CAUSTIC = 0, 1
+
+prim_dtype = np.dtype([
+    ("kind", "<i4"), ("pad0", "<i4"), ("x", "<f8"), ("y", "<f8"), ("z", "<f8"), ("radius", "<f8"),
+    ("dx", "<f8"), ("dy", "<f8"), ("dz", "<f8"), ("min_bound", "<f8"), ("max_bound", "<f8"),
+    ("red", "<f4"), ("green", "<f4"), ("blue", "<f4"), ("pad1", "<f4"),
+    ("absorb_chance", "<f8"), ("diffuse_chance", "<f8"), ("specular_chance", "<f8"),
+    ("transmission_chance", "<f8"), ("refraction", "<f8"), ("specular_coeff", "<f8")])
+photon_dtype = np.dtype([
+    ("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("power", "u1", (4,)),
+    ("dx", "<f4"), ("dy", "<f4"), ("dz", "<f4"), ("bounce", "i1"), ("pad", "u1", (3,))])
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("cam", C.c_double * 3), ("light_color", C.c_double * 3),
+                ("seed", C.c_uint64), ("flags", C.c_int32), ("order", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("closest_hit_queries", C.c_uint64), ("shadow_queries", C.c_uint64), ("gathers", C.c_uint64),
+                ("absorb_points", C.c_uint64)]
+
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-C", HERE, "-s"], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        L = C.CDLL(LIB)
+        vp, u64, i32, dp = C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(C.c_double)
+        L.orc_default_scene.argtypes = [vp]
+        L.orc_fastfloor.argtypes = [C.c_double]; L.orc_fastfloor.restype = i32
+        L.orc_prim_intersect.argtypes = [vp, dp, dp, C.c_double, dp, dp]; L.orc_prim_intersect.restype = C.c_int
+        L.orc_det_sincos.argtypes = [C.c_double, dp, dp]
+        L.orc_primary_hits.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp, u64, C.c_int, C.c_int, vp, vp, vp]
+        L.orc_emit_attempt.argtypes = [vp, C.c_int, C.c_int, u64, u64, C.c_int, dp, vp, C.POINTER(C.c_int), vp]
+        L.orc_emit_attempt.restype = C.c_int
+        L.orc_emit.argtypes = [vp, C.c_int, C.c_int, u64, C.c_int, C.c_int, dp, vp, vp]; L.orc_emit.restype = u64
+        L.orc_map_create.argtypes = [vp, C.c_int, C.c_int, u64]; L.orc_map_create.restype = vp
+        L.orc_map_destroy.argtypes = [vp]
+        L.orc_map_size.argtypes = [vp]; L.orc_map_size.restype = C.c_int
+        for f in (L.orc_knn_ref, L.orc_knn_exact, L.orc_knn_brute):
+            f.argtypes = [vp, dp, vp, vp]; f.restype = C.c_int
+        L.orc_gather.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp]
+        L.orc_gather_batch.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int]
+        L.orc_trace_pixel.argtypes = [vp, C.c_int, vp, vp, C.POINTER(RenderParams), C.c_int, C.c_int, vp, vp]
+        L.orc_trace_pixel.restype = C.c_uint32
+        L.orc_render_rows.argtypes = [vp, C.c_int, vp, vp, C.POINTER(RenderParams), C.c_int, C.c_int, C.c_int, C.c_int, vp, C.POINTER(Stats)]
+        _lib = L
+    return _lib
+
+
+def _v3(v):
+    return (C.c_double * 3)(*[float(t) for t in v])
+
+
+def default_scene():
+    s = np.zeros(7, dtype=prim_dtype)
+    lib().orc_default_scene(s.ctypes.data)
+    return s
+
+
+def prim_intersect(prim, src, direction, dt):
+    prim = np.ascontiguousarray(prim, dtype=prim_dtype)
+    res, nrm = (C.c_double * 3)(), (C.c_double * 3)()
+    hit = lib().orc_prim_intersect(prim.ctypes.data, _v3(src), _v3(direction), float(dt), res, nrm)
+    return bool(hit), np.array(res[:]), np.array(nrm[:])
+
+
+def det_sincos(x):
+    s, c = C.c_double(), C.c_double()
+    lib().orc_det_sincos(float(x), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def primary_hits(prims, width, height, seed, cam=(0, 0, -12), y0=0, y1=None):
+    y1 = height if y1 is None else y1
+    prims = np.ascontiguousarray(prims, dtype=prim_dtype)
+    n = (y1 - y0) * width
+    ids = np.empty(n, dtype=np.int32); pts = np.empty((n, 3)); nrm = np.empty((n, 3))
+    lib().orc_primary_hits(prims.ctypes.data, len(prims), width, height, _v3(cam), seed, y0, y1, ids.ctypes.data, pts.ctypes.data, nrm.ctypes.data)
+    return ids.reshape(y1 - y0, width), pts, nrm
+
+
+def emit(prims, kind, seed, n_photons, trig=TRIG_DET, light_color=(0.6, 0.6, 0.6)):
+    prims = np.ascontiguousarray(prims, dtype=prim_dtype)
+    out = np.zeros(n_photons, dtype=photon_dtype)
+    attempts = lib().orc_emit(prims.ctypes.data, len(prims), kind, seed, n_photons, trig, _v3(light_color), out.ctypes.data, None)
+    return out, attempts
+
+
+def emit_attempt(prims, kind, seed, attempt, trig=TRIG_DET, light_color=(0.6, 0.6, 0.6)):
+    prims = np.ascontiguousarray(prims, dtype=prim_dtype)
+    out = np.zeros(1, dtype=photon_dtype)
+    nd = C.c_int()
+    ok = lib().orc_emit_attempt(prims.ctypes.data, len(prims), kind, seed, attempt, trig, _v3(light_color), out.ctypes.data, C.byref(nd), None)
+    return bool(ok), out[0], nd.value
+
+
+class Map:
+    def __init__(self, photons, build_ref=False, pivot_seed=0):
+        photons = np.ascontiguousarray(photons, dtype=photon_dtype)
+        self.n = len(photons)
+        self.h = lib().orc_map_create(photons.ctypes.data, self.n, 1 if build_ref else 0, pivot_seed)
+
+    def close(self):
+        if self.h:
+            lib().orc_map_destroy(self.h); self.h = None
+
+    def _knn(self, fn, q):
+        idx = np.empty(63, dtype=np.int32); d2 = np.empty(63)
+        found = fn(self.h, _v3(q), idx.ctypes.data, d2.ctypes.data)
+        return found, idx, d2
+
+    def knn_ref(self, q): return self._knn(lib().orc_knn_ref, q)
+    def knn_exact(self, q): return self._knn(lib().orc_knn_exact, q)
+    def knn_brute(self, q): return self._knn(lib().orc_knn_brute, q)
+
+    def gather(self, kind, points, normals, order=ORDER_CANONICAL, nthreads=1):
+        points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        normals = np.ascontiguousarray(normals, dtype=np.float64).reshape(-1, 3)
+        out = np.empty_like(points)
+        lib().orc_gather_batch(self.h, kind, order, len(points), points.ctypes.data, normals.ctypes.data, out.ctypes.data, nthreads)
+        return out
+
+
+def params(width, height, seed, cam=(0, 0, -12), light_color=(0.6, 0.6, 0.6), flags=0, order=ORDER_CANONICAL):
+    rp = RenderParams()
+    rp.width, rp.height, rp.seed, rp.flags, rp.order = width, height, seed, flags, order
+    rp.cam = _v3(cam); rp.light_color = _v3(light_color)
+    return rp
+
+
+def render(prims, gmap, cmap, rp, y0=0, y1=None, ystep=1, nthreads=1, pane=None):
+    """One job per row on nthreads workers; returns (pane, Stats)."""
+    prims = np.ascontiguousarray(prims, dtype=prim_dtype)
+    y1 = rp.height if y1 is None else y1
+    if pane is None:
+        pane = np.zeros((rp.height, rp.width), dtype=np.uint32)
+    st = Stats()
+    lib().orc_render_rows(prims.ctypes.data, len(prims), gmap.h if gmap else None, cmap.h if cmap else None, C.byref(rp),
+                          y0, y1, ystep, nthreads, pane.ctypes.data, C.byref(st))
+    return pane, st

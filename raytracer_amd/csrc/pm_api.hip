@@ -1,0 +1,554 @@
+// pm_api.hip -- host side of libraytracer_amd.so: context, device buffers, kernel launches and the
+// extern "C" entry points declared in include/raytracer_amd.h.  This is the layer that stands in
+// for the reference's JobSystem (src/JobSystem.cpp): instead of queueing one job per image row for
+// CPU workers, a frame is a short chain of kernels on one HIP stream.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/raytracer_amd.h"
+#include "pm_build.h"
+#include "pm_kernels.h"
+
+namespace pm {
+hipError_t sort_pairs_u64(void *temp, size_t &temp_bytes, const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in,
+                          uint32_t *vals_out, size_t n, hipStream_t stream);
+}
+using namespace pm;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) return fail(PM_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+#define PMCHK(expr) do { int r_ = (expr); if (r_ != PM_OK) return r_; } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return PM_OK;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return fail(PM_EHIP, "hipFree failed"); }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return fail(PM_ENOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed: " + hipGetErrorString(e)); }
+        cap = want;
+        return PM_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+constexpr size_t LDS_SCENE_MAX = 48 * 1024;   // scenes up to this size are staged in LDS; larger ones are read from global memory
+constexpr int N_EVENTS = 8;
+
+struct pm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // scene
+    int nprims = 0, stride = 0;
+    bool lds = true;
+    size_t scene_b = 0;
+    DevBuf scene;
+    SceneView gv{};
+    // frame work buffers (grow only, reused across frames)
+    DevBuf geo, obj, pixel, node, tabslot, direct, radg, radc, color, clist, tab, ctr, pane;
+    uint32_t sp_cap = 0;
+    Counters *h_ctr = nullptr;   // pinned
+    uint64_t *h_u64 = nullptr;   // pinned scratch (2 words)
+    // emission / build scratch
+    DevBuf emit_tmp, emit_flag, emit_counts, emit_offs, emit_out;
+    DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, bounds;
+    hipEvent_t ev[N_EVENTS] = {};
+};
+
+struct pm_map {
+    pm_ctx *ctx = nullptr;
+    long long n = 0;
+    DevBuf records, pos4, rest, boxes;
+    MapView view{};
+};
+
+static int set_device(pm_ctx *ctx) { HIPCHK(hipSetDevice(ctx->device)); return PM_OK; }
+
+extern "C" const char *pm_last_error(void) { return g_err.c_str(); }
+
+extern "C" int pm_ctx_create(int device, pm_ctx **out) {
+    if (!out) return fail(PM_EINVAL, "pm_ctx_create: out is NULL");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(PM_EINVAL, "pm_ctx_create: no such device " + std::to_string(device));
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(PM_ESTATE, std::string("pm_ctx_create: this library is built for gfx950 (MI355X) only, device is ") + prop.gcnArchName);
+    pm_ctx *ctx = new (std::nothrow) pm_ctx();
+    if (!ctx) return fail(PM_ENOMEM, "out of host memory");
+    ctx->device = device;
+    HIPCHK(hipHostMalloc((void **)&ctx->h_ctr, sizeof(Counters), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&ctx->h_u64, 4 * sizeof(uint64_t), hipHostMallocDefault));
+    for (int i = 0; i < N_EVENTS; i++) HIPCHK(hipEventCreate(&ctx->ev[i]));
+    *out = ctx;
+    return PM_OK;
+}
+
+extern "C" int pm_ctx_destroy(pm_ctx *ctx) {
+    if (!ctx) return PM_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&ctx->scene, &ctx->geo, &ctx->obj, &ctx->pixel, &ctx->node, &ctx->tabslot, &ctx->direct, &ctx->radg, &ctx->radc,
+                      &ctx->color, &ctx->clist, &ctx->tab, &ctx->ctr, &ctx->pane, &ctx->emit_tmp, &ctx->emit_flag, &ctx->emit_counts,
+                      &ctx->emit_offs, &ctx->emit_out, &ctx->keys_in, &ctx->keys_out, &ctx->vals_in, &ctx->vals_out, &ctx->sort_tmp, &ctx->bounds};
+    for (DevBuf *b : bufs) b->release();
+    if (ctx->h_ctr) (void)hipHostFree(ctx->h_ctr);
+    if (ctx->h_u64) (void)hipHostFree(ctx->h_u64);
+    for (int i = 0; i < N_EVENTS; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    delete ctx;
+    return PM_OK;
+}
+
+extern "C" int pm_ctx_set_stream(pm_ctx *ctx, void *hip_stream) {
+    if (!ctx) return fail(PM_EINVAL, "ctx is NULL");
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return PM_OK;
+}
+
+// ---------------------------------------------------------------------------------------- scene
+extern "C" int pm_scene_upload(pm_ctx *ctx, const pm_prim *prims, int32_t n) {
+    if (!ctx || !prims || n <= 0) return fail(PM_EINVAL, "pm_scene_upload: need a context and n > 0 primitives");
+    if (n > (1 << 23)) return fail(PM_EINVAL, "pm_scene_upload: at most 2^23 primitives (object id is packed into 24 bits)");
+    PMCHK(set_device(ctx));
+    int stride = (n + 3) & ~3;
+    size_t bytes = scene_bytes(stride);
+    std::vector<unsigned char> host(bytes, 0);
+    double *g = reinterpret_cast<double *>(host.data());
+    float *rgb = reinterpret_cast<float *>(host.data() + (size_t)stride * G_NFIELDS * sizeof(double));
+    int *kind = reinterpret_cast<int *>(host.data() + (size_t)stride * (G_NFIELDS * sizeof(double) + 3 * sizeof(float)));
+    for (int i = 0; i < n; i++) {
+        const pm_prim &p = prims[i];
+        if (p.kind != 0 && p.kind != 1) return fail(PM_EINVAL, "pm_scene_upload: prim " + std::to_string(i) + " has unknown kind");
+        g[G_X * stride + i] = p.x; g[G_Y * stride + i] = p.y; g[G_Z * stride + i] = p.z;
+        g[G_RADIUS * stride + i] = p.radius;
+        g[G_DX * stride + i] = p.dx; g[G_DY * stride + i] = p.dy; g[G_DZ * stride + i] = p.dz;
+        g[G_MIN * stride + i] = p.min_bound; g[G_MAX * stride + i] = p.max_bound;
+        g[G_ABSORB * stride + i] = p.absorb_chance; g[G_DIFFUSE * stride + i] = p.diffuse_chance;
+        g[G_SPECULAR * stride + i] = p.specular_chance; g[G_TRANSMISSION * stride + i] = p.transmission_chance;
+        g[G_REFRACTION * stride + i] = p.refraction;
+        rgb[0 * stride + i] = p.red; rgb[1 * stride + i] = p.green; rgb[2 * stride + i] = p.blue;
+        // PlaneObject::intersect picks its branch from the field values (src/Scene.cpp:136,157,174)
+        if (p.kind == 0) kind[i] = PK_SPHERE;
+        else kind[i] = p.x != 0 ? PK_PLANE_X : (p.y != 0 ? PK_PLANE_Y : (p.z > 0 ? PK_PLANE_Z : PK_NEVER));
+    }
+    for (int i = n; i < stride; i++) kind[i] = PK_NEVER;
+    PMCHK(ctx->scene.ensure(bytes));
+    HIPCHK(hipMemcpyAsync(ctx->scene.p, host.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->nprims = n; ctx->stride = stride; ctx->scene_b = bytes; ctx->lds = bytes <= LDS_SCENE_MAX;
+    unsigned char *d = ctx->scene.as<unsigned char>();
+    ctx->gv.n = n; ctx->gv.stride = stride;
+    ctx->gv.g = reinterpret_cast<const double *>(d);
+    ctx->gv.rgb = reinterpret_cast<const float *>(d + (size_t)stride * G_NFIELDS * sizeof(double));
+    ctx->gv.kind = reinterpret_cast<const int *>(d + (size_t)stride * (G_NFIELDS * sizeof(double) + 3 * sizeof(float)));
+    return PM_OK;
+}
+
+#define LAUNCH_SCENE(kern, grid, block, ctx, ...)                                                                 \
+    do {                                                                                                          \
+        if ((ctx)->lds) hipLaunchKernelGGL(kern<true>, grid, block, (ctx)->scene_b, (ctx)->stream, (ctx)->gv, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kern<false>, grid, block, 0, (ctx)->stream, (ctx)->gv, __VA_ARGS__);              \
+    } while (0)
+
+// ------------------------------------------------------------------------------------- emission
+// attempts [a0, a0+count) -> first `cap` successes, in attempt order, into d_out; *total = successes in range,
+// *last = offset (in the range) of the attempt that produced record cap-1 (or count-1 if fewer successes)
+static int emit_range(pm_ctx *ctx, int kind, uint64_t seed, const double lc[3], uint64_t a0, uint64_t count, pm_photon *d_out,
+                      uint64_t cap, uint64_t *total) {
+    if (count == 0) { *total = 0; return PM_OK; }
+    if (count > (1ULL << 31)) return fail(PM_EINVAL, "emit_range: at most 2^31 attempts per call");
+    uint32_t nb = (uint32_t)((count + 255) / 256);
+    PMCHK(ctx->emit_tmp.ensure(count * sizeof(pm_photon)));
+    PMCHK(ctx->emit_flag.ensure(count));
+    PMCHK(ctx->emit_counts.ensure((size_t)nb * 4));
+    PMCHK(ctx->emit_offs.ensure(((size_t)nb + 1) * 8));
+    uint64_t K = stream_key(seed, kind == PM_MAP_GLOBAL ? KIND_EMIT_GLOBAL : KIND_EMIT_CAUSTIC);
+    V3 light = {lc[0], lc[1], lc[2]};
+    LAUNCH_SCENE(k_emit, dim3(nb), dim3(256), ctx, kind, K, light, a0, count, ctx->emit_tmp.as<pm_photon>(), ctx->emit_flag.as<uint8_t>(),
+                 ctx->emit_counts.as<uint32_t>());
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, ctx->emit_counts.as<uint32_t>(), ctx->emit_offs.as<uint64_t>(), nb);
+    hipLaunchKernelGGL(k_emit_scatter, dim3(nb), dim3(256), 0, ctx->stream, ctx->emit_tmp.as<pm_photon>(), ctx->emit_flag.as<uint8_t>(),
+                       ctx->emit_offs.as<uint64_t>(), count, d_out, cap);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(ctx->h_u64, ctx->emit_offs.as<uint64_t>() + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *total = ctx->h_u64[0];
+    return PM_OK;
+}
+
+extern "C" int pm_emit_range(pm_ctx *ctx, int32_t map_kind, uint64_t seed, const double light_color[3], uint64_t attempt_begin,
+                             uint64_t attempt_count, pm_photon *d_out, uint64_t cap, uint64_t *out_count) {
+    if (!ctx || !light_color || !out_count || (!d_out && cap)) return fail(PM_EINVAL, "pm_emit_range: NULL argument");
+    if (map_kind != PM_MAP_GLOBAL && map_kind != PM_MAP_CAUSTIC) return fail(PM_EINVAL, "pm_emit_range: bad map_kind");
+    if (ctx->nprims == 0) return fail(PM_ESTATE, "pm_emit_range: no scene uploaded");
+    PMCHK(set_device(ctx));
+    return emit_range(ctx, map_kind, seed, light_color, attempt_begin, attempt_count, d_out, cap, out_count);
+}
+
+// ---------------------------------------------------------------------------------------- build
+static int build_index(pm_map *map) {
+    pm_ctx *ctx = map->ctx;
+    long long n = map->n;
+    MapView &v = map->view;
+    memset(&v, 0, sizeof(v));
+    v.n = n;
+    if (n == 0) return PM_OK;
+    if (n > (1LL << 31) - 64) return fail(PM_EINVAL, "pm_map_build: at most 2^31-64 photons per map");
+    const pm_photon *rec = map->records.as<pm_photon>();
+    PMCHK(ctx->keys_in.ensure((size_t)n * 8)); PMCHK(ctx->keys_out.ensure((size_t)n * 8));
+    PMCHK(ctx->vals_in.ensure((size_t)n * 4)); PMCHK(ctx->vals_out.ensure((size_t)n * 4));
+    PMCHK(ctx->bounds.ensure(6 * 4));
+    PMCHK(map->pos4.ensure((size_t)n * 16)); PMCHK(map->rest.ensure((size_t)n * 16));
+    uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    HIPCHK(hipMemcpyAsync(ctx->bounds.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    unsigned nbk = (unsigned)std::min<long long>((n + 255) / 256, 2048);
+    unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_bounds, dim3(nbk), dim3(256), 0, ctx->stream, rec, n, ctx->bounds.as<uint32_t>());
+    hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, ctx->stream, rec, n, ctx->bounds.as<uint32_t>(), ctx->keys_in.as<uint64_t>(),
+                       ctx->vals_in.as<uint32_t>());
+    size_t tmp_bytes = 0;
+    HIPCHK(sort_pairs_u64(nullptr, tmp_bytes, ctx->keys_in.as<uint64_t>(), ctx->keys_out.as<uint64_t>(), ctx->vals_in.as<uint32_t>(),
+                          ctx->vals_out.as<uint32_t>(), (size_t)n, ctx->stream));
+    PMCHK(ctx->sort_tmp.ensure(tmp_bytes));
+    HIPCHK(sort_pairs_u64(ctx->sort_tmp.p, tmp_bytes, ctx->keys_in.as<uint64_t>(), ctx->keys_out.as<uint64_t>(), ctx->vals_in.as<uint32_t>(),
+                          ctx->vals_out.as<uint32_t>(), (size_t)n, ctx->stream));
+    hipLaunchKernelGGL(k_permute, dim3(nb), dim3(256), 0, ctx->stream, rec, ctx->vals_out.as<uint32_t>(), n, map->pos4.as<float4>(),
+                       map->rest.as<uint4>());
+    // level sizes
+    int cnt[MAX_LEVELS];
+    int top = 0;
+    cnt[0] = (int)((n + 63) / 64);
+    while (cnt[top] > 64) {
+        if (top + 1 >= MAX_LEVELS) return fail(PM_EINVAL, "pm_map_build: too many photons for the tree depth");
+        cnt[top + 1] = (cnt[top] + 63) / 64;
+        top++;
+    }
+    size_t total = 0;
+    for (int t = 0; t <= top; t++) total += (size_t)cnt[t];
+    PMCHK(map->boxes.ensure(total * sizeof(BoxRec)));
+    BoxRec *base = map->boxes.as<BoxRec>();
+    size_t off = 0;
+    for (int t = 0; t <= top; t++) { v.lv[t] = base + off; v.cnt[t] = cnt[t]; off += (size_t)cnt[t]; }
+    v.top = top; v.pos4 = map->pos4.as<float4>(); v.rest = map->rest.as<uint4>();
+    hipLaunchKernelGGL(k_leaf_boxes, dim3((cnt[0] + 3) / 4), dim3(256), 0, ctx->stream, v.pos4, n, const_cast<BoxRec *>(v.lv[0]), cnt[0]);
+    for (int t = 1; t <= top; t++)
+        hipLaunchKernelGGL(k_level_boxes, dim3((cnt[t] + 3) / 4), dim3(256), 0, ctx->stream, v.lv[t - 1], cnt[t - 1], const_cast<BoxRec *>(v.lv[t]), cnt[t]);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PM_OK;
+}
+
+extern "C" int pm_map_build(pm_ctx *ctx, const pm_photon *records, int64_t n, int32_t records_on_device, pm_map **out) {
+    if (!ctx || !out || n < 0 || (n > 0 && !records)) return fail(PM_EINVAL, "pm_map_build: bad argument");
+    PMCHK(set_device(ctx));
+    pm_map *map = new (std::nothrow) pm_map();
+    if (!map) return fail(PM_ENOMEM, "out of host memory");
+    map->ctx = ctx; map->n = n;
+    int rc = map->records.ensure((size_t)std::max<int64_t>(n, 1) * sizeof(pm_photon));
+    if (rc == PM_OK && n > 0) {
+        hipError_t e = hipMemcpyAsync(map->records.p, records, (size_t)n * sizeof(pm_photon),
+                                      records_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) rc = fail(PM_EHIP, std::string("copy of photon records failed: ") + hipGetErrorString(e));
+    }
+    if (rc == PM_OK) rc = build_index(map);
+    if (rc != PM_OK) { pm_map_destroy(map); return rc; }
+    *out = map;
+    return PM_OK;
+}
+
+extern "C" int pm_map_create(pm_ctx *ctx, int32_t map_kind, int64_t n, uint64_t seed, const double light_color[3], pm_map **out,
+                             uint64_t *attempts_used) {
+    if (!ctx || !out || n < 0 || !light_color) return fail(PM_EINVAL, "pm_map_create: bad argument");
+    if (map_kind != PM_MAP_GLOBAL && map_kind != PM_MAP_CAUSTIC) return fail(PM_EINVAL, "pm_map_create: bad map_kind");
+    if (ctx->nprims == 0) return fail(PM_ESTATE, "pm_map_create: no scene uploaded");
+    PMCHK(set_device(ctx));
+    pm_map *map = new (std::nothrow) pm_map();
+    if (!map) return fail(PM_ENOMEM, "out of host memory");
+    map->ctx = ctx; map->n = n;
+    int rc = map->records.ensure((size_t)std::max<int64_t>(n, 1) * sizeof(pm_photon));
+    uint64_t have = 0, next_attempt = 0;
+    // batches of consecutive attempt ranges; the result (first n successes in attempt order) does not depend on the batch size
+    double yield = map_kind == PM_MAP_GLOBAL ? 0.60 : 0.36;
+    int empty_batches = 0;
+    while (rc == PM_OK && have < (uint64_t)n) {
+        uint64_t want = (uint64_t)n - have;
+        uint64_t batch = std::min<uint64_t>((uint64_t)((double)want / yield) + 4096, 1ULL << 24);
+        uint64_t got = 0;
+        rc = emit_range(ctx, map_kind, seed, light_color, next_attempt, batch, map->records.as<pm_photon>() + have, want, &got);
+        if (rc != PM_OK) break;
+        next_attempt += batch;
+        have += std::min<uint64_t>(got, want);
+        if (got == 0 && ++empty_batches > 8) rc = fail(PM_ESTATE, "pm_map_create: no emission attempt stores a photon in this scene");
+    }
+    if (rc == PM_OK) rc = build_index(map);
+    if (rc != PM_OK) { pm_map_destroy(map); return rc; }
+    if (attempts_used) *attempts_used = next_attempt;   // upper bound: attempts issued (whole batches)
+    *out = map;
+    return PM_OK;
+}
+
+extern "C" int pm_map_size(const pm_map *map, int64_t *n) {
+    if (!map || !n) return fail(PM_EINVAL, "pm_map_size: NULL argument");
+    *n = map->n;
+    return PM_OK;
+}
+extern "C" int pm_map_download(pm_map *map, pm_photon *host_out) {
+    if (!map || (!host_out && map->n)) return fail(PM_EINVAL, "pm_map_download: NULL argument");
+    PMCHK(set_device(map->ctx));
+    if (map->n) {
+        HIPCHK(hipMemcpyAsync(host_out, map->records.p, (size_t)map->n * sizeof(pm_photon), hipMemcpyDeviceToHost, map->ctx->stream));
+        HIPCHK(hipStreamSynchronize(map->ctx->stream));
+    }
+    return PM_OK;
+}
+extern "C" int pm_map_destroy(pm_map *map) {
+    if (!map) return PM_OK;
+    if (map->ctx) { (void)hipSetDevice(map->ctx->device); (void)hipStreamSynchronize(map->ctx->stream); }
+    map->records.release(); map->pos4.release(); map->rest.release(); map->boxes.release();
+    delete map;
+    return PM_OK;
+}
+
+// --------------------------------------------------------------------------------------- gather
+static void gather_grid(long long count, unsigned &blocks, uint32_t &waves_total) {
+    long long want = (count + 3) / 4;
+    blocks = (unsigned)std::max<long long>(1, std::min<long long>(want, 256 * 8));
+    waves_total = blocks * 4;
+}
+
+extern "C" int pm_knn_query(pm_ctx *ctx, pm_map *map, int64_t m, const double *points, int32_t *idx, double *d2, int32_t *found) {
+    if (!ctx || !map || m < 0 || (m && (!points || !idx || !d2 || !found))) return fail(PM_EINVAL, "pm_knn_query: bad argument");
+    if (m == 0) return PM_OK;
+    PMCHK(set_device(ctx));
+    DevBuf dp, di, dd, df;
+    int rc = dp.ensure((size_t)m * 24);
+    if (rc == PM_OK) rc = di.ensure((size_t)m * KNN_K * 4);
+    if (rc == PM_OK) rc = dd.ensure((size_t)m * KNN_K * 8);
+    if (rc == PM_OK) rc = df.ensure((size_t)m * 4);
+    hipError_t e = hipSuccess;
+    if (rc == PM_OK) {
+        e = hipMemcpyAsync(dp.p, points, (size_t)m * 24, hipMemcpyHostToDevice, ctx->stream);
+        unsigned blocks; uint32_t waves;
+        gather_grid(m, blocks, waves);
+        if (e == hipSuccess) hipLaunchKernelGGL(k_knn_query, dim3(blocks), dim3(256), 0, ctx->stream, map->view, dp.as<double>(), (long long)m,
+                                                di.as<int32_t>(), dd.as<double>(), df.as<int32_t>(), waves);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(idx, di.p, (size_t)m * KNN_K * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d2, dd.p, (size_t)m * KNN_K * 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(found, df.p, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    dp.release(); di.release(); dd.release(); df.release();
+    if (rc != PM_OK) return rc;
+    if (e != hipSuccess) return fail(PM_EHIP, std::string("pm_knn_query: ") + hipGetErrorString(e));
+    return PM_OK;
+}
+
+extern "C" int pm_knn_gather(pm_ctx *ctx, pm_map *map, int32_t map_kind, int64_t m, const double *points, const double *normals,
+                             double *radiance, int32_t on_device) {
+    if (!ctx || !map || m < 0 || (m && (!points || !normals || !radiance))) return fail(PM_EINVAL, "pm_knn_gather: bad argument");
+    if (map_kind != PM_MAP_GLOBAL && map_kind != PM_MAP_CAUSTIC) return fail(PM_EINVAL, "pm_knn_gather: bad map_kind");
+    if (m == 0) return PM_OK;
+    PMCHK(set_device(ctx));
+    DevBuf dp, dn, dr;
+    const double *p = points, *nn = normals;
+    double *r = radiance;
+    int rc = PM_OK;
+    hipError_t e = hipSuccess;
+    if (!on_device) {
+        rc = dp.ensure((size_t)m * 24);
+        if (rc == PM_OK) rc = dn.ensure((size_t)m * 24);
+        if (rc == PM_OK) rc = dr.ensure((size_t)m * 24);
+        if (rc == PM_OK) {
+            e = hipMemcpyAsync(dp.p, points, (size_t)m * 24, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(dn.p, normals, (size_t)m * 24, hipMemcpyHostToDevice, ctx->stream);
+            p = dp.as<double>(); nn = dn.as<double>(); r = dr.as<double>();
+        }
+    }
+    if (rc == PM_OK && e == hipSuccess) {
+        unsigned blocks; uint32_t waves;
+        gather_grid(m, blocks, waves);
+        if (map_kind == PM_MAP_GLOBAL) hipLaunchKernelGGL(k_gather_points<0>, dim3(blocks), dim3(256), 0, ctx->stream, map->view, p, nn, r, (long long)m, waves);
+        else hipLaunchKernelGGL(k_gather_points<1>, dim3(blocks), dim3(256), 0, ctx->stream, map->view, p, nn, r, (long long)m, waves);
+        e = hipGetLastError();
+        if (e == hipSuccess && !on_device) e = hipMemcpyAsync(radiance, dr.p, (size_t)m * 24, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    dp.release(); dn.release(); dr.release();
+    if (rc != PM_OK) return rc;
+    if (e != hipSuccess) return fail(PM_EHIP, std::string("pm_knn_gather: ") + hipGetErrorString(e));
+    return PM_OK;
+}
+
+// --------------------------------------------------------------------------------------- frames
+static int make_frame_params(pm_ctx *ctx, const pm_render_params *rp, FrameParams &fp) {
+    if (!ctx || !rp) return fail(PM_EINVAL, "NULL argument");
+    if (ctx->nprims == 0) return fail(PM_ESTATE, "no scene uploaded");
+    if (rp->width <= 0 || rp->height <= 0 || (long long)rp->width * rp->height > (1LL << 27))
+        return fail(PM_EINVAL, "pane must be between 1x1 and 2^27 pixels (pixel index * 32 is the RNG item)");
+    if (rp->world < 1 || rp->rank < 0 || rp->rank >= rp->world) return fail(PM_EINVAL, "bad rank/world");
+    fp.width = rp->width; fp.height = rp->height;
+    fp.cam = {rp->cam[0], rp->cam[1], rp->cam[2]};
+    fp.light = {rp->light_color[0], rp->light_color[1], rp->light_color[2]};
+    fp.K = stream_key(rp->seed, KIND_PIXEL);
+    fp.flags = rp->flags; fp.rank = rp->rank; fp.world = rp->world;
+    return PM_OK;
+}
+
+extern "C" int pm_primary_hits(pm_ctx *ctx, const pm_render_params *rp, int32_t y0, int32_t y1, int32_t *ids, double *points, double *normals) {
+    FrameParams fp;
+    PMCHK(make_frame_params(ctx, rp, fp));
+    if (!ids || y0 < 0 || y1 > rp->height || y0 > y1) return fail(PM_EINVAL, "pm_primary_hits: bad row range or ids is NULL");
+    long long total = (long long)(y1 - y0) * rp->width;
+    if (total == 0) return PM_OK;
+    PMCHK(set_device(ctx));
+    DevBuf di, dp, dn;
+    int rc = di.ensure((size_t)total * 4);
+    if (rc == PM_OK && points) rc = dp.ensure((size_t)total * 24);
+    if (rc == PM_OK && normals) rc = dn.ensure((size_t)total * 24);
+    hipError_t e = hipSuccess;
+    if (rc == PM_OK) {
+        LAUNCH_SCENE(k_primary_hits, dim3((unsigned)((total + 255) / 256)), dim3(256), ctx, fp, (int)y0, (int)y1, di.as<int32_t>(),
+                     points ? dp.as<double>() : nullptr, normals ? dn.as<double>() : nullptr);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(ids, di.p, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && points) e = hipMemcpyAsync(points, dp.p, (size_t)total * 24, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && normals) e = hipMemcpyAsync(normals, dn.p, (size_t)total * 24, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    di.release(); dp.release(); dn.release();
+    if (rc != PM_OK) return rc;
+    if (e != hipSuccess) return fail(PM_EHIP, std::string("pm_primary_hits: ") + hipGetErrorString(e));
+    return PM_OK;
+}
+
+static int ensure_sp(pm_ctx *ctx, uint32_t cap) {
+    if (cap <= ctx->sp_cap) return PM_OK;
+    size_t c = (size_t)cap + cap / 8 + 1024;
+    PMCHK(ctx->geo.ensure(c * 6 * 8)); PMCHK(ctx->obj.ensure(c * 4)); PMCHK(ctx->pixel.ensure(c * 4));
+    PMCHK(ctx->node.ensure(c * 4)); PMCHK(ctx->tabslot.ensure(c * 4)); PMCHK(ctx->direct.ensure(c * 8));
+    PMCHK(ctx->radg.ensure(c * 3 * 8)); PMCHK(ctx->radc.ensure(c * 3 * 8)); PMCHK(ctx->color.ensure(c * 4));
+    ctx->sp_cap = (uint32_t)c;
+    return PM_OK;
+}
+static SPQueue sp_queue(pm_ctx *ctx) {
+    SPQueue q;
+    q.geo = ctx->geo.as<double>(); q.obj = ctx->obj.as<int32_t>(); q.pixel = ctx->pixel.as<uint32_t>();
+    q.node = ctx->node.as<uint32_t>(); q.tabslot = ctx->tabslot.as<uint32_t>(); q.direct = ctx->direct.as<double>();
+    q.rad_g = ctx->radg.as<double>(); q.rad_c = ctx->radc.as<double>(); q.color = ctx->color.as<uint32_t>();
+    q.cap = ctx->sp_cap;
+    return q;
+}
+
+extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_params *rp, uint32_t *pane, int32_t pane_on_device,
+                         pm_stats *stats) {
+    FrameParams fp;
+    PMCHK(make_frame_params(ctx, rp, fp));
+    if (!pane) return fail(PM_EINVAL, "pm_render: pane is NULL");
+    if (!(rp->flags & PM_FLAG_NO_GLOBAL) && !gmap) return fail(PM_EINVAL, "pm_render: global map missing (or pass PM_FLAG_NO_GLOBAL)");
+    if (!(rp->flags & PM_FLAG_NO_CAUSTIC) && !cmap) return fail(PM_EINVAL, "pm_render: caustic map missing (or pass PM_FLAG_NO_CAUSTIC)");
+    if ((gmap && gmap->ctx != ctx) || (cmap && cmap->ctx != ctx)) return fail(PM_EINVAL, "pm_render: map belongs to another context");
+    PMCHK(set_device(ctx));
+    const int W = rp->width, H = rp->height;
+    const int nblk = (H + PM_ROW_BLOCK - 1) / PM_ROW_BLOCK;
+    const int owned = nblk > rp->rank ? (nblk - rp->rank + rp->world - 1) / rp->world : 0;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (owned == 0) return PM_OK;
+    const size_t owned_px = (size_t)owned * PM_ROW_BLOCK * W;
+
+    uint32_t *d_pane = pane;
+    if (!pane_on_device) { PMCHK(ctx->pane.ensure((size_t)W * H * 4)); d_pane = ctx->pane.as<uint32_t>(); }
+    PMCHK(ctx->ctr.ensure(sizeof(Counters)));
+    PMCHK(ctx->clist.ensure(owned_px * 4));
+    PMCHK(ensure_sp(ctx, (uint32_t)std::min<size_t>(owned_px + owned_px / 4, 0xFFFFFF00u)));
+    Counters *d_ctr = ctx->ctr.as<Counters>();
+    dim3 grid_px((W + 15) / 16, owned), block(256);
+
+    HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+    uint32_t n_sp0 = 0, n_complex = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        HIPCHK(hipMemsetAsync(d_ctr, 0, sizeof(Counters), ctx->stream));
+        SPQueue q = sp_queue(ctx);
+        LAUNCH_SCENE(k_primary, grid_px, block, ctx, fp, d_pane, d_ctr, q, ctx->clist.as<uint32_t>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(ctx->h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        n_sp0 = ctx->h_ctr->n_sp; n_complex = ctx->h_ctr->n_complex;
+        size_t need = (size_t)n_sp0 + (size_t)15 * n_complex;   // every node of a bounced pixel's tree may absorb
+        if (need > 0xFFFFFF00u) return fail(PM_EINVAL, "pm_render: too many shade points for one call; split the frame over more ranks");
+        if (need <= ctx->sp_cap) break;
+        PMCHK(ensure_sp(ctx, (uint32_t)need));   // queues were reallocated: run the primary pass again
+    }
+    HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+    uint32_t n_sp = n_sp0, n_secondary = 0;
+    SPQueue q = sp_queue(ctx);
+    NodeEntry *tab = nullptr;
+    if (n_complex) {
+        PMCHK(ctx->tab.ensure((size_t)n_complex * 16 * sizeof(NodeEntry)));
+        tab = ctx->tab.as<NodeEntry>();
+        LAUNCH_SCENE(k_secondary, dim3((n_complex + 255) / 256), block, ctx, fp, d_ctr, q, ctx->clist.as<uint32_t>(), n_complex, tab);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(ctx->h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        n_sp = ctx->h_ctr->n_sp; n_secondary = ctx->h_ctr->n_secondary;
+    }
+    HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+    int n_gathers = 0;
+    if (n_sp) {
+        LAUNCH_SCENE(k_shadow, dim3((n_sp + 255) / 256), block, ctx, fp, q, n_sp);
+        HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+        unsigned blocks; uint32_t waves;
+        gather_grid(n_sp, blocks, waves);
+        if (!(rp->flags & PM_FLAG_NO_GLOBAL)) { hipLaunchKernelGGL(k_gather<0>, dim3(blocks), block, 0, ctx->stream, gmap->view, q, n_sp, waves); n_gathers++; }
+        HIPCHK(hipEventRecord(ctx->ev[4], ctx->stream));
+        if (!(rp->flags & PM_FLAG_NO_CAUSTIC)) { hipLaunchKernelGGL(k_gather<1>, dim3(blocks), block, 0, ctx->stream, cmap->view, q, n_sp, waves); n_gathers++; }
+        HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));
+        LAUNCH_SCENE(k_shade, dim3((n_sp + 255) / 256), block, ctx, fp, q, n_sp, d_pane, tab);
+    } else {
+        for (int i = 3; i <= 5; i++) HIPCHK(hipEventRecord(ctx->ev[i], ctx->stream));
+    }
+    if (n_complex) LAUNCH_SCENE(k_resolve, dim3((n_complex + 255) / 256), block, ctx, ctx->clist.as<uint32_t>(), n_complex, tab, d_pane);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev[6], ctx->stream));
+    if (!pane_on_device) {
+        for (int b = rp->rank; b < nblk; b += rp->world) {
+            size_t y0 = (size_t)b * PM_ROW_BLOCK, y1 = std::min<size_t>(y0 + PM_ROW_BLOCK, (size_t)H);
+            HIPCHK(hipMemcpyAsync(pane + y0 * W, d_pane + y0 * W, (y1 - y0) * W * 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (stats) {
+        size_t px = 0;
+        for (int b = rp->rank; b < nblk; b += rp->world) px += (std::min<size_t>((size_t)(b + 1) * PM_ROW_BLOCK, (size_t)H) - (size_t)b * PM_ROW_BLOCK) * W;
+        stats->closest_hit_queries = px + n_secondary;
+        stats->shadow_queries = (uint64_t)25 * n_sp;
+        stats->gathers = (uint64_t)n_gathers * n_sp;
+        stats->absorb_points = n_sp;
+        stats->complex_pixels = n_complex;
+        (void)hipEventElapsedTime(&stats->ms_primary, ctx->ev[0], ctx->ev[1]);
+        (void)hipEventElapsedTime(&stats->ms_secondary, ctx->ev[1], ctx->ev[2]);
+        (void)hipEventElapsedTime(&stats->ms_shadow, ctx->ev[2], ctx->ev[3]);
+        (void)hipEventElapsedTime(&stats->ms_gather_global, ctx->ev[3], ctx->ev[4]);
+        (void)hipEventElapsedTime(&stats->ms_gather_caustic, ctx->ev[4], ctx->ev[5]);
+        (void)hipEventElapsedTime(&stats->ms_resolve, ctx->ev[5], ctx->ev[6]);
+        (void)hipEventElapsedTime(&stats->ms_total, ctx->ev[0], ctx->ev[6]);
+    }
+    return PM_OK;
+}

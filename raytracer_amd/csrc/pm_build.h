@@ -1,0 +1,225 @@
+// pm_build.h -- photon emission (one attempt per lane, ordered compaction) and the GPU build
+// of the 64-ary BVH over Morton-sorted photons.
+#pragma once
+#include "pm_device.h"
+#include "pm_knn.h"
+#include "../../include/raytracer_amd.h"
+
+namespace pm {
+
+// ------------------------------------------------------------------ emission
+// One pass of the outer loop of createPhotonMap (src/PhotonMap.cpp:288-367) or
+// createCausticPhotonMap (:400-484) per lane.  flag[t] = 1 and tmp[t] = record when the attempt
+// stores a photon.  block_counts[b] = successes in block b (for the ordered compaction).
+constexpr int EMIT_MAX_BOUNCES = 64;   // the reference loops until absorb/miss; bounded here so every wave exits
+
+template <bool LDS>
+__global__ __launch_bounds__(256) void k_emit(SceneView gs, int map_kind, uint64_t K, V3 light_color, uint64_t a0, uint64_t count,
+                                               pm_photon *tmp, uint8_t *flag, uint32_t *block_counts) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    SceneView sv = gs;
+    if (LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool stored = false;
+    if (t < count) {
+        uint64_t IK = item_key(K, a0 + t);
+        uint32_t j = 0;
+        V3 power = light_color;
+        double x0 = draw(IK, j++) * 2 - 1;
+        double z0 = draw(IK, j++) * 2 + 3;
+        V3 src = {x0, 4.95, z0};
+        double sin_theta = sqrt(draw(IK, j++));
+        double cos_theta = sqrt(1 - sin_theta * sin_theta);
+        double psi = draw(IK, j++) * 6.2831853;
+        double sp, cp;
+        det_sincos(psi, sp, cp);
+        V3 dir = {sin_theta * cp, map_kind == PM_MAP_GLOBAL ? -cos_theta : -2 * cos_theta, sin_theta * sp};
+        normalize(dir);
+        int bounces = 0, exclude = -1;
+        bool specular_bounce = false;
+        V3 res = {0, 0, 0}, nrm = {0, 0, 0};
+        while (bounces < EMIT_MAX_BOUNCES) {
+            bounces++;
+            int obj = scene_intersect(sv, src, dir, exclude, 0.0, res, nrm);
+            if (obj < 0) break;
+            double chance = draw(IK, j++);
+            if (bounces > 3) chance = 1;
+            double kd = sv.f(G_DIFFUSE, obj), ks = sv.f(G_SPECULAR, obj), kt = sv.f(G_TRANSMISSION, obj);
+            if (chance < kd + ks) {
+                V3 n1 = nrm;
+                double k = n1.x * dir.x + n1.y * dir.y + n1.z * dir.z;
+                n1.x *= k; n1.y *= k; n1.z *= k;
+                n1.x *= 2; n1.y *= 2; n1.z *= 2;
+                src = res;
+                dir.x = dir.x - n1.x; dir.y = dir.y - n1.y; dir.z = dir.z - n1.z;
+                normalize(dir);
+                power.x *= (double)sv.rgb[0 * sv.stride + obj]; power.y *= (double)sv.rgb[1 * sv.stride + obj]; power.z *= (double)sv.rgb[2 * sv.stride + obj];
+                if (map_kind == PM_MAP_GLOBAL) exclude = obj;   // :327 ; the caustic loop always passes nullptr (:420)
+                specular_bounce = true;
+                continue;
+            } else if (chance < kd + ks + kt) {
+                double n = 1 / sv.f(G_REFRACTION, obj);
+                double d = nrm.x * dir.x + nrm.y * dir.y + nrm.z * dir.z;
+                V3 n1 = {nrm.x * d, nrm.y * d, nrm.z * d};
+                n1.x = dir.x - n1.x; n1.y = dir.y - n1.y; n1.z = dir.z - n1.z;
+                n1.x *= n; n1.y *= n; n1.z *= n;
+                double s = 1 - (n * n) * (1 - d * d);
+                double sq = sqrt(s);
+                V3 n2 = {nrm.x * sq, nrm.y * sq, nrm.z * sq};
+                n1.x += -n2.x; n1.y += -n2.y; n1.z += -n2.z;
+                src.x = res.x + n1.x * 0.01; src.y = res.y + n1.y * 0.01; src.z = res.z + n1.z * 0.01;
+                dir = n1;
+                normalize(dir);
+                exclude = -1;
+                specular_bounce = true;
+                continue;
+            } else {
+                if (map_kind == PM_MAP_CAUSTIC && !specular_bounce) break;   // :463-466
+                pm_photon ph;
+                ph.x = (float)res.x; ph.y = (float)res.y; ph.z = (float)res.z;
+                ph.power[0] = (uint8_t)fastfloor(power.x * 0xFF);
+                ph.power[1] = (uint8_t)fastfloor(power.y * 0xFF);
+                ph.power[2] = (uint8_t)fastfloor(power.z * 0xFF);
+                ph.power[3] = 255;
+                ph.dx = (float)dir.x; ph.dy = (float)dir.y; ph.dz = (float)dir.z;
+                ph.bounce = (int8_t)bounces;
+                ph.pad[0] = ph.pad[1] = ph.pad[2] = 0;
+                tmp[t] = ph;
+                stored = true;
+            }
+            break;
+        }
+        flag[t] = stored ? 1 : 0;
+    }
+    int c = __syncthreads_count(stored ? 1 : 0);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = (uint32_t)c;
+}
+
+// exclusive scan of nb block counts by one 1024-thread block; offs[nb] = total
+__global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t *counts, uint64_t *offs, uint32_t nb) {
+    __shared__ uint64_t buf[1024];
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nb; base += 1024) {
+        uint32_t i = base + threadIdx.x;
+        uint64_t v = i < nb ? counts[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int s = 1; s < 1024; s <<= 1) {
+            uint64_t add = threadIdx.x >= (unsigned)s ? buf[threadIdx.x - s] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < nb) offs[i] = carry + buf[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += buf[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offs[nb] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_emit_scatter(const pm_photon *tmp, const uint8_t *flag, const uint64_t *offs, uint64_t count,
+                                                       pm_photon *out, uint64_t cap) {
+    __shared__ uint32_t wave_cnt[4];
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool f = t < count && flag[t] != 0;
+    unsigned long long m = __ballot(f);
+    if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = 0;
+    for (int w = 0; w < wave; w++) before += wave_cnt[w];
+    if (f) {
+        uint64_t dst = offs[blockIdx.x] + before + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL));
+        if (dst < cap) out[dst] = tmp[t];
+    }
+}
+
+// ------------------------------------------------------------------ index build
+__device__ inline uint32_t f2ord(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ inline float ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
+
+// bounds[0..2] = min xyz, bounds[3..5] = max xyz as order-preserving uints (init: 0xFFFFFFFF / 0)
+__global__ __launch_bounds__(256) void k_bounds(const pm_photon *ph, long long n, uint32_t *bounds) {
+    uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0, 0, 0};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        uint32_t v[3] = {f2ord(ph[i].x), f2ord(ph[i].y), f2ord(ph[i].z)};
+        for (int a = 0; a < 3; a++) { mn[a] = min(mn[a], v[a]); mx[a] = max(mx[a], v[a]); }
+    }
+    for (int a = 0; a < 3; a++) {
+        for (int s = 1; s < 64; s <<= 1) { mn[a] = min(mn[a], (uint32_t)__shfl_xor((int)mn[a], s)); mx[a] = max(mx[a], (uint32_t)__shfl_xor((int)mx[a], s)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&bounds[a], mn[a]); atomicMax(&bounds[3 + a], mx[a]); }
+    }
+}
+
+__device__ inline uint64_t spread21(uint64_t v) {   // 21 bits -> every third bit
+    v &= 0x1FFFFFULL;
+    v = (v | v << 32) & 0x1F00000000FFFFULL;
+    v = (v | v << 16) & 0x1F0000FF0000FFULL;
+    v = (v | v << 8) & 0x100F00F00F00F00FULL;
+    v = (v | v << 4) & 0x10C30C30C30C30C3ULL;
+    v = (v | v << 2) & 0x1249249249249249ULL;
+    return v;
+}
+__global__ __launch_bounds__(256) void k_morton(const pm_photon *ph, long long n, const uint32_t *bounds, uint64_t *keys, uint32_t *vals) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float p[3] = {ph[i].x, ph[i].y, ph[i].z};
+    uint64_t code = 0;
+    for (int a = 0; a < 3; a++) {
+        float lo = ord2f(bounds[a]), hi = ord2f(bounds[3 + a]);
+        float ext = hi - lo;
+        float t = ext > 0.f ? (p[a] - lo) / ext : 0.f;
+        uint32_t qv = (uint32_t)fminf(fmaxf(t * 2097152.0f, 0.f), 2097151.0f);
+        code |= spread21(qv) << a;
+    }
+    keys[i] = code;
+    vals[i] = (uint32_t)i;
+}
+
+// sorted order -> the two 16-byte streams the gather reads
+__global__ __launch_bounds__(256) void k_permute(const pm_photon *ph, const uint32_t *order, long long n, float4 *pos4, uint4 *rest) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t o = order[i];
+    const uint4 *rec = reinterpret_cast<const uint4 *>(&ph[o]);
+    uint4 a = rec[0], b = rec[1];   // a = x y z power ; b = dx dy dz bounce
+    pos4[i] = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(o));
+    rest[i] = make_uint4(b.x, b.y, b.z, a.w);
+}
+
+__device__ inline float wave_min_f(float v) { for (int s = 1; s < 64; s <<= 1) v = fminf(v, __shfl_xor(v, s)); return v; }
+__device__ inline float wave_max_f(float v) { for (int s = 1; s < 64; s <<= 1) v = fmaxf(v, __shfl_xor(v, s)); return v; }
+
+// one wave per leaf: box of photons [64*leaf, 64*leaf+64)
+__global__ __launch_bounds__(256) void k_leaf_boxes(const float4 *pos4, long long n, BoxRec *boxes, int nleaves) {
+    int leaf = (int)((blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6);
+    int lane = threadIdx.x & 63;
+    if (leaf >= nleaves) return;
+    long long i = (long long)leaf * 64 + lane;
+    const float INF = __int_as_float(0x7F800000);
+    float4 p = i < n ? pos4[i] : make_float4(INF, INF, INF, 0.f);
+    float4 pm = i < n ? p : make_float4(-INF, -INF, -INF, 0.f);
+    BoxRec b;
+    b.lox = wave_min_f(p.x); b.loy = wave_min_f(p.y); b.loz = wave_min_f(p.z); b.pad0 = 0.f;
+    b.hix = wave_max_f(pm.x); b.hiy = wave_max_f(pm.y); b.hiz = wave_max_f(pm.z); b.pad1 = 0.f;
+    if (lane == 0) boxes[leaf] = b;
+}
+// one wave per parent: union of child boxes [64*node, 64*node+64)
+__global__ __launch_bounds__(256) void k_level_boxes(const BoxRec *child, int nchild, BoxRec *parent, int nparent) {
+    int node = (int)((blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6);
+    int lane = threadIdx.x & 63;
+    if (node >= nparent) return;
+    long long i = (long long)node * 64 + lane;
+    const float INF = __int_as_float(0x7F800000);
+    BoxRec c = {INF, INF, INF, 0.f, -INF, -INF, -INF, 0.f};
+    if (i < nchild) c = child[i];
+    BoxRec b;
+    b.lox = wave_min_f(c.lox); b.loy = wave_min_f(c.loy); b.loz = wave_min_f(c.loz); b.pad0 = 0.f;
+    b.hix = wave_max_f(c.hix); b.hiy = wave_max_f(c.hiy); b.hiz = wave_max_f(c.hiz); b.pad1 = 0.f;
+    if (lane == 0) parent[node] = b;
+}
+
+}  // namespace pm

@@ -1,0 +1,375 @@
+// pm_kernels.h -- the gfx950 kernels of the frame pipeline.
+//
+//   k_primary        one lane per pixel (8x8 pixel tile per wave): primary ray + closest hit,
+//                    classifies the pixel, wave-ballot compaction of absorb points ("shade points")
+//                    and of pixels that bounce (reflect / refract) into a second queue
+//   k_secondary      one lane per bounced pixel: the traceRay recursion as an explicit-stack state
+//                    machine (shared mutable (src,ray) pair); emits further shade points
+//   k_shadow         one lane per shade point: 25 shadow any-hit rays + direct term
+//   k_gather<KIND>   one WAVE per shade point: exact 63-NN + radiance estimate (pm_knn.h)
+//   k_shade          one lane per shade point: clamp, colour, 8-bit pack; final pixel for simple pixels
+//   k_resolve        one lane per bounced pixel: folds its node table bottom-up into the final pixel
+#pragma once
+#include "pm_device.h"
+#include "pm_knn.h"
+
+namespace pm {
+
+struct FrameParams {
+    int width, height;
+    V3 cam;
+    V3 light;
+    uint64_t K;          // stream key (seed, KIND_PIXEL)
+    int flags;
+    int rank, world;
+};
+
+struct Counters { uint32_t n_sp, n_complex, n_secondary, pad; };
+
+// shade point queue (SoA)
+struct SPQueue {
+    double *geo;         // [6][cap]: px py pz nx ny nz
+    int32_t *obj;        // [cap]
+    uint32_t *pixel;     // [cap]
+    uint32_t *node;      // [cap] node id | 0x80000000 when the point belongs to a bounced pixel's table
+    uint32_t *tabslot;   // [cap] index into the node table for bounced pixels
+    double *direct;      // [cap]
+    double *rad_g;       // [3][cap]
+    double *rad_c;       // [3][cap]
+    uint32_t *color;     // [cap] absorb_res
+    uint32_t cap;
+};
+
+constexpr uint32_t NODE_COMPLEX = 0x80000000u;
+
+__device__ inline bool is_light_patch(const V3 &r) {   // src/Raytrace.cpp:43
+    return r.y > 4.95 && r.x > -1 && r.x < 1 && r.z > 3 && r.z < 5;
+}
+__device__ inline uint32_t light_colour(const V3 &lc) { // src/Raytrace.cpp:46
+    return (0xFFu << 24) | ((uint32_t)imin(fastfloor(lc.x * 0xFF) + 50, 0xFF) << 16) |
+           ((uint32_t)imin(fastfloor(lc.y * 0xFF) + 50, 0xFF) << 8) | (uint32_t)imin(fastfloor(lc.z * 0xFF) + 50, 0xFF);
+}
+// the mix at src/Raytrace.cpp:245-257
+__device__ inline uint32_t mix_colour(uint32_t reflect_res, uint32_t refract_res, uint32_t absorb_res, double ks, double kt, double ka) {
+    float sred = ((reflect_res >> 16) & 0xFF) / 255.0f, sgreen = ((reflect_res >> 8) & 0xFF) / 255.0f, sblue = (reflect_res & 0xFF) / 255.0f;
+    float tred = ((refract_res >> 16) & 0xFF) / 255.0f, tgreen = ((refract_res >> 8) & 0xFF) / 255.0f, tblue = (refract_res & 0xFF) / 255.0f;
+    float ared = ((absorb_res >> 16) & 0xFF) / 255.0f, agreen = ((absorb_res >> 8) & 0xFF) / 255.0f, ablue = (absorb_res & 0xFF) / 255.0f;
+    uint32_t red = (uint32_t)fastfloor((sred * ks + tred * kt + ared * ka) * 255);
+    uint32_t green = (uint32_t)fastfloor((sgreen * ks + tgreen * kt + agreen * ka) * 255);
+    uint32_t blue = (uint32_t)fastfloor((sblue * ks + tblue * kt + ablue * ka) * 255);
+    return (0xFFu << 24) | (red << 16) | (green << 8) | blue;
+}
+
+__device__ inline void sp_store(const SPQueue &q, uint32_t slot, const V3 &res, const V3 &nrm, int obj, uint32_t pixel, uint32_t node, uint32_t tabslot) {
+    if (slot >= q.cap) return;   // capacity is sized for the worst case on the host; belt and braces
+    q.geo[0 * (size_t)q.cap + slot] = res.x; q.geo[1 * (size_t)q.cap + slot] = res.y; q.geo[2 * (size_t)q.cap + slot] = res.z;
+    q.geo[3 * (size_t)q.cap + slot] = nrm.x; q.geo[4 * (size_t)q.cap + slot] = nrm.y; q.geo[5 * (size_t)q.cap + slot] = nrm.z;
+    q.obj[slot] = obj; q.pixel[slot] = pixel; q.node[slot] = node; q.tabslot[slot] = tabslot;
+}
+
+// pixel of this lane: 16x16 tile per 256-thread block, 8x8 per wave; blockIdx.y walks owned row blocks
+__device__ inline bool tile_pixel(const FrameParams &fp, int &x, int &y) {
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    int yb = blockIdx.y * fp.world + fp.rank;
+    y = yb * 16 + (wave >> 1) * 8 + (lane >> 3);
+    return x < fp.width && y < fp.height;
+}
+
+template <bool LDS>
+__global__ __launch_bounds__(256) void k_primary(SceneView gs, FrameParams fp, uint32_t *pane, Counters *ctr, SPQueue q, uint32_t *complex_list) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    SceneView sv = gs;
+    if (LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
+    int x, y;
+    bool valid = tile_pixel(fp, x, y);
+    int lane = threadIdx.x & 63;
+    bool emit_sp = false, emit_cx = false;
+    V3 res = {0, 0, 0}, nrm = {0, 0, 0};
+    int obj = -1;
+    uint32_t pixel = 0;
+    if (valid) {
+        pixel = (uint32_t)x + (uint32_t)y * (uint32_t)fp.width;
+        V3 ray = primary_ray(fp.width, fp.height, fp.cam, fp.K, pixel, x, y);
+        double dt = draw(item_key(fp.K, (uint64_t)pixel * 32u + 1u), 0);   // traceRay's own draw, src/Raytrace.cpp:39
+        obj = scene_intersect(sv, fp.cam, ray, -1, dt, res, nrm);
+        if (obj < 0) pane[pixel] = 0xFF000000u;
+        else if (is_light_patch(res)) pane[pixel] = light_colour(fp.light);
+        else if (sv.f(G_TRANSMISSION, obj) > 0 || sv.f(G_SPECULAR, obj) > 0) emit_cx = true;
+        else if (sv.f(G_ABSORB, obj) > 0) emit_sp = true;
+        else pane[pixel] = mix_colour(0, 0, 0, sv.f(G_SPECULAR, obj), sv.f(G_TRANSMISSION, obj), sv.f(G_ABSORB, obj));
+    }
+    // wavefront-ballot compaction: one atomic per wave and queue
+    unsigned long long m = __ballot(emit_sp);
+    if (m) {
+        int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&ctr->n_sp, (uint32_t)__popcll(m));
+        base = __shfl(base, leader);
+        if (emit_sp) sp_store(q, base + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL)), res, nrm, obj, pixel, 1u, 0u);
+    }
+    m = __ballot(emit_cx);
+    if (m) {
+        int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&ctr->n_complex, (uint32_t)__popcll(m));
+        base = __shfl(base, leader);
+        if (emit_cx) complex_list[base + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL))] = pixel;
+    }
+}
+
+// hit ids / points / normals only (parity gate for primary rays)
+template <bool LDS>
+__global__ __launch_bounds__(256) void k_primary_hits(SceneView gs, FrameParams fp, int y0, int y1, int32_t *ids, double *pts, double *nrms) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    SceneView sv = gs;
+    if (LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)(y1 - y0) * fp.width;
+    if (t >= total) return;
+    int x = (int)(t % fp.width), y = y0 + (int)(t / fp.width);
+    uint32_t pixel = (uint32_t)x + (uint32_t)y * (uint32_t)fp.width;
+    V3 ray = primary_ray(fp.width, fp.height, fp.cam, fp.K, pixel, x, y);
+    double dt = draw(item_key(fp.K, (uint64_t)pixel * 32u + 1u), 0);
+    V3 res = {0, 0, 0}, nrm = {0, 0, 0};
+    int obj = scene_intersect(sv, fp.cam, ray, -1, dt, res, nrm);
+    ids[t] = obj;
+    if (pts) { pts[3 * t] = res.x; pts[3 * t + 1] = res.y; pts[3 * t + 2] = res.z; }
+    if (nrms) { nrms[3 * t] = nrm.x; nrms[3 * t + 1] = nrm.y; nrms[3 * t + 2] = nrm.z; }
+}
+
+// node table of a bounced pixel: 16 entries (node ids 1..15), two words each
+//   a: 0 = not visited, 1 = constant colour in b, 2 = object (obj id in bits 8..) with absorb slot in b (0xFFFFFFFF = none)
+struct NodeEntry { uint32_t a, b; };
+
+template <bool LDS>
+__global__ __launch_bounds__(256) void k_secondary(SceneView gs, FrameParams fp, Counters *ctr, SPQueue q, const uint32_t *complex_list,
+                                                    uint32_t n_complex, NodeEntry *tab) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    SceneView sv = gs;
+    if (LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_complex) return;
+    uint32_t pixel = complex_list[c];
+    int x = (int)(pixel % (uint32_t)fp.width), y = (int)(pixel / (uint32_t)fp.width);
+    NodeEntry *my = tab + (size_t)c * 16;
+    for (int i = 0; i < 16; i++) { my[i].a = 0; my[i].b = 0; }
+
+    struct Frame { V3 hit, nrm; int obj; int stage; };
+    Frame fr[4];
+    V3 src = fp.cam;
+    V3 ray = primary_ray(fp.width, fp.height, fp.cam, fp.K, pixel, x, y);
+    int depth = 0, exclude = -1;
+    uint32_t node = 1, nsec = 0;
+    for (;;) {
+        // ---- enter traceRay(src, ray, exclude, bounce = depth) : src/Raytrace.cpp:32-47
+        bool returned = false;
+        if (depth > 3) returned = true;   // bounce > MAX_BOUNCES: opaque black, no draw, no table entry
+        else {
+            double dt = draw(item_key(fp.K, (uint64_t)pixel * 32u + node), 0);
+            if (depth > 0) nsec++;
+            V3 res = {0, 0, 0}, nrm = {0, 0, 0};
+            int obj = scene_intersect(sv, src, ray, exclude, dt, res, nrm);
+            if (obj < 0) { my[node].a = 1; my[node].b = 0xFF000000u; returned = true; }
+            else if (is_light_patch(res)) { my[node].a = 1; my[node].b = light_colour(fp.light); returned = true; }
+            else { fr[depth].hit = res; fr[depth].nrm = nrm; fr[depth].obj = obj; fr[depth].stage = 0; }
+        }
+        if (returned) { depth--; node >>= 1; }
+        // ---- resume frames until one of them makes a recursive call
+        bool descend = false;
+        while (depth >= 0 && !descend) {
+            Frame &f = fr[depth];
+            int obj = f.obj;
+            if (f.stage == 0) {
+                f.stage = 1;
+                if (sv.f(G_TRANSMISSION, obj) > 0) {   // refract, src/Raytrace.cpp:52-71
+                    double n = 1 / sv.f(G_REFRACTION, obj);
+                    double d = f.nrm.x * ray.x + f.nrm.y * ray.y + f.nrm.z * ray.z;
+                    V3 n1 = {f.nrm.x * d, f.nrm.y * d, f.nrm.z * d};
+                    n1.x = ray.x - n1.x; n1.y = ray.y - n1.y; n1.z = ray.z - n1.z;
+                    n1.x *= n; n1.y *= n; n1.z *= n;
+                    double s = 1 - (n * n) * (1 - d * d);
+                    double sq = sqrt(s);
+                    V3 n2 = {f.nrm.x * sq, f.nrm.y * sq, f.nrm.z * sq};
+                    n1.x += -n2.x; n1.y += -n2.y; n1.z += -n2.z;
+                    src.x = f.hit.x + n1.x * 0.01; src.y = f.hit.y + n1.y * 0.01; src.z = f.hit.z + n1.z * 0.01;
+                    ray = n1;
+                    normalize(ray);
+                    exclude = -1; node = node * 2; depth++; descend = true;
+                }
+            } else if (f.stage == 1) {
+                f.stage = 2;
+                if (sv.f(G_SPECULAR, obj) > 0) {       // reflect whatever `ray` now holds, src/Raytrace.cpp:73-82
+                    V3 n1 = f.nrm;
+                    double k = n1.x * ray.x + n1.y * ray.y + n1.z * ray.z;
+                    n1.x *= k; n1.y *= k; n1.z *= k;
+                    n1.x *= 2; n1.y *= 2; n1.z *= 2;
+                    src = f.hit;
+                    ray.x = ray.x - n1.x; ray.y = ray.y - n1.y; ray.z = ray.z - n1.z;
+                    normalize(ray);
+                    exclude = obj; node = node * 2 + 1; depth++; descend = true;
+                }
+            } else {
+                uint32_t slot = 0xFFFFFFFFu;
+                if (sv.f(G_ABSORB, obj) > 0) {          // absorb branch is evaluated later, from the queue
+                    slot = atomicAdd(&ctr->n_sp, 1u);
+                    sp_store(q, slot, f.hit, f.nrm, obj, pixel, node | NODE_COMPLEX, c * 16 + node);
+                }
+                my[node].a = 2u | ((uint32_t)obj << 8);
+                my[node].b = slot;
+                depth--; node >>= 1;
+            }
+        }
+        if (depth < 0) break;
+    }
+    if (nsec) atomicAdd(&ctr->n_secondary, nsec);
+}
+
+// shadow loop + direct term, src/Raytrace.cpp:174-212
+template <bool LDS>
+__global__ __launch_bounds__(256) void k_shadow(SceneView gs, FrameParams fp, SPQueue q, uint32_t n_sp) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    SceneView sv = gs;
+    if (LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_sp) return;
+    V3 p = {q.geo[0 * (size_t)q.cap + s], q.geo[1 * (size_t)q.cap + s], q.geo[2 * (size_t)q.cap + s]};
+    V3 nrm = {q.geo[3 * (size_t)q.cap + s], q.geo[4 * (size_t)q.cap + s], q.geo[5 * (size_t)q.cap + s]};
+    int obj = q.obj[s];
+    uint64_t IK = item_key(fp.K, (uint64_t)q.pixel[s] * 32u + (q.node[s] & 31u));
+    int light_count = 0;
+    V3 shadow_ray = {0, 0, 0}, result = {0, 0, 0}, normal = {0, 0, 0};
+    for (int i = 0; i < 25; i++) {
+        double x0 = draw(IK, 1 + 3 * i) * 2 - 1;
+        double z0 = draw(IK, 2 + 3 * i) * 2 + 3;
+        double y0 = 4.95;
+        shadow_ray.x = x0 - p.x; shadow_ray.y = y0 - p.y; shadow_ray.z = z0 - p.z;
+        double max_dist = shadow_ray.x * shadow_ray.x + shadow_ray.y * shadow_ray.y + shadow_ray.z * shadow_ray.z;
+        normalize(shadow_ray);
+        double dt = draw(IK, 3 + 3 * i);
+        for (int k = 0; k < sv.n; k++) {
+            if (k == obj) continue;
+            if (prim_intersect(sv, k, p, shadow_ray, dt, result, normal)) {
+                double ds = (p.x - result.x) * (p.x - result.x) + (p.y - result.y) * (p.y - result.y) + (p.z - result.z) * (p.z - result.z);
+                if (ds > max_dist) continue;
+                light_count++;
+                break;
+            }
+        }
+    }
+    double direct = 0;
+    if (light_count < 25) {
+        double d = nrm.x * shadow_ray.x + nrm.y * shadow_ray.y + nrm.z * shadow_ray.z;
+        if (d > 0) direct += d * 0.2 * (1 - (light_count / (double)25));
+        // the Blinn term at src/Raytrace.cpp:215-227 only feeds a variable that is never read
+    }
+    if (fp.flags & 4) direct = 0;
+    q.direct[s] = direct;
+}
+
+// one wave per shade point
+template <int KIND>
+__global__ __launch_bounds__(256) void k_gather(MapView m, SPQueue q, uint32_t n_sp, uint32_t waves_total) {
+    uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    int lane = threadIdx.x & 63;
+    double *out = KIND == 0 ? q.rad_g : q.rad_c;
+    for (uint32_t s = wave; s < n_sp; s += waves_total) {
+        V3 p = {q.geo[0 * (size_t)q.cap + s], q.geo[1 * (size_t)q.cap + s], q.geo[2 * (size_t)q.cap + s]};
+        V3 nrm = {q.geo[3 * (size_t)q.cap + s], q.geo[4 * (size_t)q.cap + s], q.geo[5 * (size_t)q.cap + s]};
+        double R, G, B;
+        knn_gather<KIND>(m, p, nrm, R, G, B);
+        if (lane == 0) { out[0 * (size_t)q.cap + s] = R; out[1 * (size_t)q.cap + s] = G; out[2 * (size_t)q.cap + s] = B; }
+    }
+}
+
+// standalone gather on caller-provided points (pm_knn_gather): points/normals/radiance are [m][3]
+template <int KIND>
+__global__ __launch_bounds__(256) void k_gather_points(MapView m, const double *pts, const double *nrms, double *rad, long long count, uint32_t waves_total) {
+    uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    int lane = threadIdx.x & 63;
+    for (long long s = wave; s < count; s += waves_total) {
+        V3 p = {pts[3 * s], pts[3 * s + 1], pts[3 * s + 2]};
+        V3 nrm = {nrms[3 * s], nrms[3 * s + 1], nrms[3 * s + 2]};
+        double R, G, B;
+        knn_gather<KIND>(m, p, nrm, R, G, B);
+        if (lane == 0) { rad[3 * s] = R; rad[3 * s + 1] = G; rad[3 * s + 2] = B; }
+    }
+}
+
+// raw k-NN (pm_knn_query): idx = emission index, ascending (d2, idx)
+__global__ __launch_bounds__(256) void k_knn_query(MapView m, const double *pts, long long count, int32_t *idx, double *d2, int32_t *found, uint32_t waves_total) {
+    uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    int lane = threadIdx.x & 63;
+    for (long long s = wave; s < count; s += waves_total) {
+        V3 p = {pts[3 * s], pts[3 * s + 1], pts[3 * s + 2]};
+        KnnState st;
+        knn_query(st, m, p);
+        bool has = st.best.d < __longlong_as_double(0x7FF0000000000000LL);
+        int f = __popcll(__ballot(has));
+        if (f > KNN_K) f = KNN_K;
+        if (lane < KNN_K) {
+            bool ok = lane < f;
+            idx[s * KNN_K + lane] = ok ? (int32_t)st.best.o : -1;
+            d2[s * KNN_K + lane] = ok ? st.best.d : 0.0;
+        }
+        if (lane == 0) found[s] = f;
+    }
+}
+
+// clamp / colour / pack, src/Raytrace.cpp:230-242 ; simple pixels also get their final mix (:245-257)
+template <bool LDS>
+__global__ __launch_bounds__(256) void k_shade(SceneView gs, FrameParams fp, SPQueue q, uint32_t n_sp, uint32_t *pane, NodeEntry *tab) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    SceneView sv = gs;
+    if (LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_sp) return;
+    int obj = q.obj[s];
+    double direct = q.direct[s];
+    double gr = 0, gg = 0, gb = 0, cr = 0, cg = 0, cb = 0;
+    if (!(fp.flags & 1)) { gr = q.rad_g[0 * (size_t)q.cap + s]; gg = q.rad_g[1 * (size_t)q.cap + s]; gb = q.rad_g[2 * (size_t)q.cap + s]; }
+    if (!(fp.flags & 2)) { cr = q.rad_c[0 * (size_t)q.cap + s]; cg = q.rad_c[1 * (size_t)q.cap + s]; cb = q.rad_c[2 * (size_t)q.cap + s]; }
+    double rr = direct + cr + gr; if (rr > 1) rr = 1;
+    double rg = direct + cg + gg; if (rg > 1) rg = 1;
+    double rb = direct + cb + gb; if (rb > 1) rb = 1;
+    uint32_t red = (uint32_t)fastfloor((double)sv.rgb[0 * sv.stride + obj] * rr * 0xFF);
+    uint32_t green = (uint32_t)fastfloor((double)sv.rgb[1 * sv.stride + obj] * rg * 0xFF);
+    uint32_t blue = (uint32_t)fastfloor((double)sv.rgb[2 * sv.stride + obj] * rb * 0xFF);
+    uint32_t absorb_res = (0xFFu << 24) | (red << 16) | (green << 8) | blue;
+    q.color[s] = absorb_res;
+    uint32_t node = q.node[s];
+    if (node & NODE_COMPLEX) tab[q.tabslot[s]].b = absorb_res;   // slot -> colour, consumed by k_resolve
+    else pane[q.pixel[s]] = mix_colour(0, 0, absorb_res, sv.f(G_SPECULAR, obj), sv.f(G_TRANSMISSION, obj), sv.f(G_ABSORB, obj));
+}
+
+template <bool LDS>
+__global__ __launch_bounds__(256) void k_resolve(SceneView gs, const uint32_t *complex_list, uint32_t n_complex, const NodeEntry *tab, uint32_t *pane) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    SceneView sv = gs;
+    if (LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_complex) return;
+    const NodeEntry *my = tab + (size_t)c * 16;
+    uint32_t col[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) col[i] = 0;   // a branch that was not taken contributes 0 (refract_res / reflect_res initial value)
+#pragma unroll
+    for (int node = 15; node >= 1; node--) {
+        NodeEntry e = my[node];
+        uint32_t v = 0;
+        if (e.a == 1) v = e.b;
+        else if ((e.a & 0xFF) == 2) {
+            int obj = (int)(e.a >> 8);
+            double ks = sv.f(G_SPECULAR, obj), kt = sv.f(G_TRANSMISSION, obj), ka = sv.f(G_ABSORB, obj);
+            // children at depth 4 return opaque black (src/Raytrace.cpp:33-35); channels are 0 either way
+            uint32_t refract_res = (kt > 0) ? (node < 8 ? col[2 * node] : 0xFF000000u) : 0u;
+            uint32_t reflect_res = (ks > 0) ? (node < 8 ? col[2 * node + 1] : 0xFF000000u) : 0u;
+            uint32_t absorb_res = (ka > 0) ? e.b : 0u;
+            v = mix_colour(reflect_res, refract_res, absorb_res, ks, kt, ka);
+        }
+        col[node] = v;
+    }
+    pane[complex_list[c]] = col[1];
+}
+
+}  // namespace pm

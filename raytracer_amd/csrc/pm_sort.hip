@@ -1,0 +1,14 @@
+// pm_sort.hip -- stable LSD radix sort of (63-bit Morton key, photon index) pairs.
+// Sorting is the one library primitive of the index build (rocPRIM, ROCm's own device library);
+// the hot kernels (trace, shadow, gather) are hand written.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <stdint.h>
+
+namespace pm {
+hipError_t sort_pairs_u64(void *temp, size_t &temp_bytes, const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in,
+                          uint32_t *vals_out, size_t n, hipStream_t stream) {
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 63, stream);
+}
+}  // namespace pm
