@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE config 2: the reference's default Cornell scene at
+1440x1440, 1 spp, 1,000,000 global + 1,000,000 caustic photons, k = 63, 25 shadow rays, depth <= 3.
+
+A step is ONE WHOLE FRAME of renderScene (reference src/Raytrace.cpp:301-343): emit both photon maps,
+build their indices, trace / shade every pixel, pane complete on rank 0.  The scene is resident in HBM
+before the timed region; nothing else is.  With --gpus N the one frame is split over N ranks (strong
+scaling): emission attempts by range + one all-gather of 32-byte photon records, image rows by
+interleaved 16-row blocks + a gather of the row blocks to rank 0.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints one JSON line (rank 0).  `value` = Mrays/s = (closest-hit + shadow any-hit queries of the whole
+frame) / step time, all ranks.  `roofline` is for the dominant kernel (the k-NN gather), timed with HIP
+events on the library's stream inside the same timed steps.  `cpu_baseline` is the CPU oracle
+(oracle/pm_oracle.c, a restatement of the reference pinned against the compiled reference) rendering a
+bounded row sample of the SAME frame with the SAME photons on the host cores -- the checker used as a
+yardstick, never as the product path.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_GATHER = 63 * 32      # k photon records of 32 B
+HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(frame, args, cores):
+    """Oracle ("port") on the host cores: every `stride`-th row of the same frame, same photon maps."""
+    import numpy as np
+    from oracle import orc_py
+    scene = orc_py.default_scene()
+    gmap = orc_py.Map(frame.maps[0].download())
+    cmap = orc_py.Map(frame.maps[1].download())
+    rp = orc_py.params(args.width, args.height, args.seed)
+    stride = args.cpu_row_stride
+    # start inside the box (the top/bottom quarter of a 1440x1440 frame misses the scene)
+    t0 = time.perf_counter()
+    pane, st = orc_py.render(scene, gmap, cmap, rp, y0=stride // 2, y1=args.height, ystep=stride, nthreads=cores)
+    dt = time.perf_counter() - t0
+    rows = len(range(stride // 2, args.height, stride))
+    rays = st.closest_hit_queries + st.shadow_queries
+    gmap.close(); cmap.close()
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"rows {stride // 2}::{stride} of the same {args.width}x{args.height} frame ({rows} rows, {rays} rays, "
+                      f"{st.gathers} gathers) with the same 2x{args.photons} photons (CPU index build not timed), {dt:.2f} s",
+            "gathers_per_s": st.gathers / dt, "seconds": dt}, pane
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=1440)
+    ap.add_argument("--height", type=int, default=1440)
+    ap.add_argument("--photons", type=int, default=1000000)
+    ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-row-stride", type=int, default=12)
+    ap.add_argument("--cpu-cores", type=int, default=0)
+    ap.add_argument("--check", action="store_true", help="compare the CPU sample rows with the GPU pane")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import raytracer_amd as ra
+    from raytracer_amd.frame import GpuFrame
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    ctx = ra.Context(local_rank)
+    ctx.upload_scene(ra.default_scene())      # the input that is resident before the timed region
+    frame = GpuFrame(ctx, args.width, args.height, args.photons, args.seed, rank=rank, world=world,
+                     dist=dist if world > 1 else None)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        frame.step()
+    sync()
+    phase = {k: 0.0 for k in ("ms_primary", "ms_secondary", "ms_shadow", "ms_gather_global", "ms_gather_caustic", "ms_resolve", "ms_total")}
+    t_maps = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ta = time.perf_counter()
+        frame.build_maps()
+        torch.cuda.synchronize()
+        t_maps += time.perf_counter() - ta
+        st = frame.render()
+        frame.gather_pane()
+        for k in phase:
+            phase[k] += getattr(st, k)
+    sync()
+    dt = time.perf_counter() - t0
+
+    # whole-job totals
+    tot = torch.tensor([dt, float(st.closest_hit_queries), float(st.shadow_queries), float(st.gathers), float(st.absorb_points),
+                        phase["ms_gather_global"], phase["ms_gather_caustic"], phase["ms_total"], t_maps], dtype=torch.float64, device="cuda")
+    if world > 1:
+        mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tot.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt = float(mx[0]); rays = float(sm[1] + sm[2]); gathers = float(sm[3]); sp_local = float(tot[4])
+        g_ms, c_ms = float(mx[5]), float(mx[6])
+    else:
+        rays = float(tot[1] + tot[2]); gathers = float(tot[3]); sp_local = float(tot[4]); g_ms, c_ms = float(tot[5]), float(tot[6])
+
+    out = None
+    if rank == 0:
+        step_s = dt / args.steps
+        # dominant kernel: k_gather<global> / k_gather<caustic>; one launch each per step, sp_local gathers per launch on this rank
+        dom = "k_gather<0> (global map)" if phase["ms_gather_global"] >= phase["ms_gather_caustic"] else "k_gather<1> (caustic map)"
+        dom_ms = max(phase["ms_gather_global"], phase["ms_gather_caustic"]) / args.steps
+        achieved = ALGO_BYTES_PER_GATHER * sp_local / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/sec + photon-gathers/sec at 1440p, 1/2/4/8 GPUs; frame time (s)",
+            "value": rays / step_s / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"default Cornell scene {args.width}x{args.height}, 1 spp, {args.photons} global + {args.photons} caustic photons, "
+                                   f"k=63, 25 shadow rays, depth<=3 (BASELINE config 2); step = emit both maps + build indices + trace/shade + pane on rank 0",
+                       "seed": args.seed, "parallelism": f"rows x{world} (16-row blocks), emission attempts x{world} + all-gather"},
+            "gathers_per_s": gathers / step_s, "frame_time_s": step_s, "rays_per_frame": rays, "gathers_per_frame": gathers,
+            "phases_ms_rank0": {**{k: v / args.steps for k, v in phase.items()}, "maps_emit_and_build_wall": t_maps / args.steps * 1e3},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "note": f"algorithmic bytes = {ALGO_BYTES_PER_GATHER} B x {int(sp_local)} gathers per launch; avg launch {dom_ms:.3f} ms (HIP events on the library stream)"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            cores = args.cpu_cores or min(os.cpu_count() or 1, 16)
+            cb, cpane = cpu_baseline(frame, args, cores)
+            if args.check:
+                gp = frame.pane.cpu().numpy().view(np.uint32)
+                rows = slice(args.cpu_row_stride // 2, args.height, args.cpu_row_stride)
+                cb["sample_rows_bit_identical_to_gpu"] = bool(np.array_equal(gp[rows], cpane[rows]))
+            out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+    frame.close()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

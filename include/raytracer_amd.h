@@ -124,6 +124,11 @@ int pm_map_destroy(pm_map *map);
 int pm_knn_query(pm_ctx *ctx, pm_map *map, int64_t m, const double *points, int32_t *idx, double *d2,
                  int32_t *found);
 
+/* pm_knn_query plus per-query work counters (diagnostics; no counterpart in the reference):
+ * work[4q..4q+3] = tree nodes visited, leaves visited, sort-merges, single insertions. */
+int pm_knn_profile(pm_ctx *ctx, pm_map *map, int64_t m, const double *points, int32_t *idx, double *d2,
+                   int32_t *found, uint32_t *work);
+
 /* find_nearest_photons + the radiance loop of src/Raytrace.cpp:97-131 (map_kind GLOBAL) or :136-170
  * (CAUSTIC) for m points; radiance is m x 3 doubles.  on_device: 0 = host arrays, 1 = device arrays. */
 int pm_knn_gather(pm_ctx *ctx, pm_map *map, int32_t map_kind, int64_t m, const double *points,

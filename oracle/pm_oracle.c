@@ -656,25 +656,22 @@ void orc_gather(const orc_map *m, int map_kind, int order, const double p[3], co
         }
         rgb[0] /= norm_k * r; rgb[1] /= norm_k * r; rgb[2] /= norm_k * r;
     } else {
-        /* canonical order: ascending (d2, idx); pairwise (xor-butterfly) tree over 64 slots.
-         * r = largest of the selected d2 (the reference's distances[0]). */
+        /* canonical (order-independent) sum: r = largest of the selected d2 (the reference's
+         * distances[0]); every term is truncated to a multiple of 2^-56 and the terms are added as
+         * 64-bit integers (0 <= term <= 1, at most 63 terms: no overflow), so the result does not
+         * depend on the order in which an index delivers the photons.  Photons at exactly d2 == r have
+         * weight (1 - d2/r) == 0, so ties at the k-th distance cannot change the sum either. */
         int found = orc_knn_exact(m, p, idx, d2);
         if (found == 0) return;
         double r = d2[found - 1];
-        double c[3][64];
-        for (int i = 0; i < 64; i++) {
-            double t[3] = {0, 0, 0};
-            if (i < found) photon_term(&m->ph[idx[i]], map_kind, p, nrm, d2[i], r, t);
-            c[0][i] = t[0]; c[1][i] = t[1]; c[2][i] = t[2];
+        int64_t acc[3] = {0, 0, 0};
+        for (int i = 0; i < found; i++) {
+            if (!(d2[i] < r)) continue;
+            double t[3];
+            photon_term(&m->ph[idx[i]], map_kind, p, nrm, d2[i], r, t);
+            for (int ch = 0; ch < 3; ch++) acc[ch] += (int64_t)(t[ch] * 72057594037927936.0);
         }
-        for (int ch = 0; ch < 3; ch++) {
-            for (int s = 1; s < 64; s <<= 1) {
-                double t[64];
-                for (int i = 0; i < 64; i++) t[i] = c[ch][i] + c[ch][i ^ s];
-                memcpy(c[ch], t, sizeof(t));
-            }
-            rgb[ch] = c[ch][0] / (norm_k * r);
-        }
+        for (int ch = 0; ch < 3; ch++) rgb[ch] = ((double)acc[ch] * (1.0 / 72057594037927936.0)) / (norm_k * r);
     }
 }
 

@@ -51,13 +51,14 @@ class PMError(RuntimeError):
 
 EXPORTS = ["pm_ctx_create", "pm_ctx_destroy", "pm_ctx_set_stream", "pm_last_error", "pm_scene_upload",
            "pm_emit_range", "pm_map_build", "pm_map_create", "pm_map_size", "pm_map_download", "pm_map_destroy",
-           "pm_knn_query", "pm_knn_gather", "pm_primary_hits", "pm_render"]
+           "pm_knn_query", "pm_knn_profile", "pm_knn_gather", "pm_primary_hits", "pm_render"]
 
 _lib = None
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libraytracer_amd.so")
+    # PM_LIB selects another build of the same library (A/B experiments); default is the in-tree build
+    return os.environ.get("PM_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libraytracer_amd.so")
 
 
 def load_library():
@@ -78,6 +79,7 @@ def load_library():
         "pm_map_create": [vp, i32, i64, u64, C.POINTER(C.c_double), C.POINTER(vp), C.POINTER(u64)],
         "pm_map_size": [vp, C.POINTER(i64)], "pm_map_download": [vp, vp], "pm_map_destroy": [vp],
         "pm_knn_query": [vp, vp, i64, vp, vp, vp, vp],
+        "pm_knn_profile": [vp, vp, i64, vp, vp, vp, vp, vp],
         "pm_knn_gather": [vp, vp, i32, i64, vp, vp, vp, i32],
         "pm_primary_hits": [vp, C.POINTER(RenderParams), i32, i32, vp, vp, vp],
         "pm_render": [vp, vp, vp, C.POINTER(RenderParams), vp, i32, C.POINTER(Stats)],
@@ -204,6 +206,16 @@ class Context:
         found = np.empty(m, dtype=np.int32)
         _check(self.lib.pm_knn_query(self.handle, pmap.handle, m, points.ctypes.data, idx.ctypes.data, d2.ctypes.data, found.ctypes.data))
         return found, idx, d2
+
+    def knn_profile(self, pmap, points):
+        """knn_query plus per-query work counters [nodes, leaves, sort-merges, insertions]."""
+        points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        m = len(points)
+        idx = np.empty((m, PM_K), dtype=np.int32); d2 = np.empty((m, PM_K)); found = np.empty(m, dtype=np.int32)
+        work = np.empty((m, 4), dtype=np.uint32)
+        _check(self.lib.pm_knn_profile(self.handle, pmap.handle, m, points.ctypes.data, idx.ctypes.data, d2.ctypes.data,
+                                       found.ctypes.data, work.ctypes.data))
+        return found, idx, d2, work
 
     def knn_gather(self, pmap, points, normals, kind=None):
         points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)

@@ -327,38 +327,49 @@ extern "C" int pm_map_destroy(pm_map *map) {
 }
 
 // --------------------------------------------------------------------------------------- gather
+// grid for the wave-per-query kernels: a multiple of 8 blocks (one group per XCD), at most 8 blocks per CU
 static void gather_grid(long long count, unsigned &blocks, uint32_t &waves_total) {
     long long want = (count + 3) / 4;
-    blocks = (unsigned)std::max<long long>(1, std::min<long long>(want, 256 * 8));
+    blocks = (unsigned)std::max<long long>(8, std::min<long long>((want + 7) / 8 * 8, 256 * 8));
     waves_total = blocks * 4;
 }
 
-extern "C" int pm_knn_query(pm_ctx *ctx, pm_map *map, int64_t m, const double *points, int32_t *idx, double *d2, int32_t *found) {
+static int knn_query_impl(pm_ctx *ctx, pm_map *map, int64_t m, const double *points, int32_t *idx, double *d2, int32_t *found, uint32_t *work) {
     if (!ctx || !map || m < 0 || (m && (!points || !idx || !d2 || !found))) return fail(PM_EINVAL, "pm_knn_query: bad argument");
     if (m == 0) return PM_OK;
     PMCHK(set_device(ctx));
-    DevBuf dp, di, dd, df;
+    DevBuf dp, di, dd, df, dw;
     int rc = dp.ensure((size_t)m * 24);
     if (rc == PM_OK) rc = di.ensure((size_t)m * KNN_K * 4);
     if (rc == PM_OK) rc = dd.ensure((size_t)m * KNN_K * 8);
     if (rc == PM_OK) rc = df.ensure((size_t)m * 4);
+    if (rc == PM_OK && work) rc = dw.ensure((size_t)m * 16);
     hipError_t e = hipSuccess;
     if (rc == PM_OK) {
         e = hipMemcpyAsync(dp.p, points, (size_t)m * 24, hipMemcpyHostToDevice, ctx->stream);
         unsigned blocks; uint32_t waves;
         gather_grid(m, blocks, waves);
         if (e == hipSuccess) hipLaunchKernelGGL(k_knn_query, dim3(blocks), dim3(256), 0, ctx->stream, map->view, dp.as<double>(), (long long)m,
-                                                di.as<int32_t>(), dd.as<double>(), df.as<int32_t>(), waves);
+                                                di.as<int32_t>(), dd.as<double>(), df.as<int32_t>(), work ? dw.as<uint32_t>() : nullptr);
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(idx, di.p, (size_t)m * KNN_K * 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(d2, dd.p, (size_t)m * KNN_K * 8, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(found, df.p, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && work) e = hipMemcpyAsync(work, dw.p, (size_t)m * 16, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     }
-    dp.release(); di.release(); dd.release(); df.release();
+    dp.release(); di.release(); dd.release(); df.release(); dw.release();
     if (rc != PM_OK) return rc;
     if (e != hipSuccess) return fail(PM_EHIP, std::string("pm_knn_query: ") + hipGetErrorString(e));
     return PM_OK;
+}
+
+extern "C" int pm_knn_query(pm_ctx *ctx, pm_map *map, int64_t m, const double *points, int32_t *idx, double *d2, int32_t *found) {
+    return knn_query_impl(ctx, map, m, points, idx, d2, found, nullptr);
+}
+extern "C" int pm_knn_profile(pm_ctx *ctx, pm_map *map, int64_t m, const double *points, int32_t *idx, double *d2, int32_t *found, uint32_t *work) {
+    if (m && !work) return fail(PM_EINVAL, "pm_knn_profile: work is NULL");
+    return knn_query_impl(ctx, map, m, points, idx, d2, found, work);
 }
 
 extern "C" int pm_knn_gather(pm_ctx *ctx, pm_map *map, int32_t map_kind, int64_t m, const double *points, const double *normals,
@@ -385,8 +396,8 @@ extern "C" int pm_knn_gather(pm_ctx *ctx, pm_map *map, int32_t map_kind, int64_t
     if (rc == PM_OK && e == hipSuccess) {
         unsigned blocks; uint32_t waves;
         gather_grid(m, blocks, waves);
-        if (map_kind == PM_MAP_GLOBAL) hipLaunchKernelGGL(k_gather_points<0>, dim3(blocks), dim3(256), 0, ctx->stream, map->view, p, nn, r, (long long)m, waves);
-        else hipLaunchKernelGGL(k_gather_points<1>, dim3(blocks), dim3(256), 0, ctx->stream, map->view, p, nn, r, (long long)m, waves);
+        if (map_kind == PM_MAP_GLOBAL) hipLaunchKernelGGL(k_gather_points<0>, dim3(blocks), dim3(256), 0, ctx->stream, map->view, p, nn, r, (long long)m);
+        else hipLaunchKernelGGL(k_gather_points<1>, dim3(blocks), dim3(256), 0, ctx->stream, map->view, p, nn, r, (long long)m);
         e = hipGetLastError();
         if (e == hipSuccess && !on_device) e = hipMemcpyAsync(radiance, dr.p, (size_t)m * 24, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -516,9 +527,9 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
         HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
         unsigned blocks; uint32_t waves;
         gather_grid(n_sp, blocks, waves);
-        if (!(rp->flags & PM_FLAG_NO_GLOBAL)) { hipLaunchKernelGGL(k_gather<0>, dim3(blocks), block, 0, ctx->stream, gmap->view, q, n_sp, waves); n_gathers++; }
+        if (!(rp->flags & PM_FLAG_NO_GLOBAL)) { hipLaunchKernelGGL(k_gather<0>, dim3(blocks), block, 0, ctx->stream, gmap->view, q, n_sp); n_gathers++; }
         HIPCHK(hipEventRecord(ctx->ev[4], ctx->stream));
-        if (!(rp->flags & PM_FLAG_NO_CAUSTIC)) { hipLaunchKernelGGL(k_gather<1>, dim3(blocks), block, 0, ctx->stream, cmap->view, q, n_sp, waves); n_gathers++; }
+        if (!(rp->flags & PM_FLAG_NO_CAUSTIC)) { hipLaunchKernelGGL(k_gather<1>, dim3(blocks), block, 0, ctx->stream, cmap->view, q, n_sp); n_gathers++; }
         HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));
         LAUNCH_SCENE(k_shade, dim3((n_sp + 255) / 256), block, ctx, fp, q, n_sp, d_pane, tab);
     } else {

@@ -1,8 +1,9 @@
 // pm_build.h -- photon emission (one attempt per lane, ordered compaction) and the GPU build
-// of the 64-ary BVH over Morton-sorted photons.
+// of the 64-ary BVH over Hilbert-sorted photons.
 #pragma once
 #include "pm_device.h"
 #include "pm_knn.h"
+#include "pm_hilbert.h"
 #include "../../include/raytracer_amd.h"
 
 namespace pm {
@@ -154,28 +155,19 @@ __global__ __launch_bounds__(256) void k_bounds(const pm_photon *ph, long long n
     }
 }
 
-__device__ inline uint64_t spread21(uint64_t v) {   // 21 bits -> every third bit
-    v &= 0x1FFFFFULL;
-    v = (v | v << 32) & 0x1F00000000FFFFULL;
-    v = (v | v << 16) & 0x1F0000FF0000FFULL;
-    v = (v | v << 8) & 0x100F00F00F00F00FULL;
-    v = (v | v << 4) & 0x10C30C30C30C30C3ULL;
-    v = (v | v << 2) & 0x1249249249249249ULL;
-    return v;
-}
 __global__ __launch_bounds__(256) void k_morton(const pm_photon *ph, long long n, const uint32_t *bounds, uint64_t *keys, uint32_t *vals) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float p[3] = {ph[i].x, ph[i].y, ph[i].z};
-    uint64_t code = 0;
+    // one cubic grid over the largest extent (anisotropic scaling would distort the curve's locality)
+    float ext = 0.f;
+    for (int a = 0; a < 3; a++) ext = fmaxf(ext, ord2f(bounds[3 + a]) - ord2f(bounds[a]));
+    uint32_t qv[3];
     for (int a = 0; a < 3; a++) {
-        float lo = ord2f(bounds[a]), hi = ord2f(bounds[3 + a]);
-        float ext = hi - lo;
-        float t = ext > 0.f ? (p[a] - lo) / ext : 0.f;
-        uint32_t qv = (uint32_t)fminf(fmaxf(t * 2097152.0f, 0.f), 2097151.0f);
-        code |= spread21(qv) << a;
+        float t = ext > 0.f ? (p[a] - ord2f(bounds[a])) / ext : 0.f;
+        qv[a] = (uint32_t)fminf(fmaxf(t * 2097152.0f, 0.f), 2097151.0f);
     }
-    keys[i] = code;
+    keys[i] = hilbert3<21>(qv[0], qv[1], qv[2]);
     vals[i] = (uint32_t)i;
 }
 

@@ -269,50 +269,71 @@ __global__ __launch_bounds__(256) void k_shadow(SceneView gs, FrameParams fp, SP
 
 // one wave per shade point
 template <int KIND>
-__global__ __launch_bounds__(256) void k_gather(MapView m, SPQueue q, uint32_t n_sp, uint32_t waves_total) {
-    uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+__global__ __launch_bounds__(256) void k_gather(MapView m, SPQueue q, uint32_t n_sp) {
+    __shared__ KnnBuf bufs[4];
+    KnnBuf *buf = &bufs[threadIdx.x >> 6];
     int lane = threadIdx.x & 63;
     double *out = KIND == 0 ? q.rad_g : q.rad_c;
-    for (uint32_t s = wave; s < n_sp; s += waves_total) {
+    // blocks b, b+8, b+16, ... share an XCD (and its L2): give each XCD one contiguous eighth of the
+    // queue (= a band of the image, so a compact part of the photon map) and stride its waves over it
+    uint32_t xcd = blockIdx.x & 7, nx = gridDim.x >> 3;
+    uint32_t lo = (uint32_t)(((uint64_t)n_sp * xcd) >> 3), hi = (uint32_t)(((uint64_t)n_sp * (xcd + 1)) >> 3);
+    uint32_t wl = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6), wpx = nx * 4;
+    for (uint32_t s = lo + wl; s < hi; s += wpx) {
         V3 p = {q.geo[0 * (size_t)q.cap + s], q.geo[1 * (size_t)q.cap + s], q.geo[2 * (size_t)q.cap + s]};
         V3 nrm = {q.geo[3 * (size_t)q.cap + s], q.geo[4 * (size_t)q.cap + s], q.geo[5 * (size_t)q.cap + s]};
         double R, G, B;
-        knn_gather<KIND>(m, p, nrm, R, G, B);
+        knn_gather<KIND>(buf, m, p, nrm, R, G, B);
         if (lane == 0) { out[0 * (size_t)q.cap + s] = R; out[1 * (size_t)q.cap + s] = G; out[2 * (size_t)q.cap + s] = B; }
     }
 }
 
 // standalone gather on caller-provided points (pm_knn_gather): points/normals/radiance are [m][3]
 template <int KIND>
-__global__ __launch_bounds__(256) void k_gather_points(MapView m, const double *pts, const double *nrms, double *rad, long long count, uint32_t waves_total) {
-    uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+__global__ __launch_bounds__(256) void k_gather_points(MapView m, const double *pts, const double *nrms, double *rad, long long count) {
+    __shared__ KnnBuf bufs[4];
+    KnnBuf *buf = &bufs[threadIdx.x >> 6];
     int lane = threadIdx.x & 63;
-    for (long long s = wave; s < count; s += waves_total) {
+    long long xcd = blockIdx.x & 7, nx = gridDim.x >> 3;
+    long long lo = (count * xcd) >> 3, hi = (count * (xcd + 1)) >> 3;
+    long long wl = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6), wpx = nx * 4;
+    for (long long s = lo + wl; s < hi; s += wpx) {
         V3 p = {pts[3 * s], pts[3 * s + 1], pts[3 * s + 2]};
         V3 nrm = {nrms[3 * s], nrms[3 * s + 1], nrms[3 * s + 2]};
         double R, G, B;
-        knn_gather<KIND>(m, p, nrm, R, G, B);
+        knn_gather<KIND>(buf, m, p, nrm, R, G, B);
         if (lane == 0) { rad[3 * s] = R; rad[3 * s + 1] = G; rad[3 * s + 2] = B; }
     }
 }
 
 // raw k-NN (pm_knn_query): idx = emission index, ascending (d2, idx)
-__global__ __launch_bounds__(256) void k_knn_query(MapView m, const double *pts, long long count, int32_t *idx, double *d2, int32_t *found, uint32_t waves_total) {
-    uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+__global__ __launch_bounds__(256) void k_knn_query(MapView m, const double *pts, long long count, int32_t *idx, double *d2, int32_t *found, uint32_t *work) {
+    __shared__ KnnBuf bufs[4];
+    KnnBuf *buf = &bufs[threadIdx.x >> 6];
     int lane = threadIdx.x & 63;
+    long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves_total = ((long long)gridDim.x * blockDim.x) >> 6;
     for (long long s = wave; s < count; s += waves_total) {
         V3 p = {pts[3 * s], pts[3 * s + 1], pts[3 * s + 2]};
         KnnState st;
-        knn_query(st, m, p);
-        bool has = st.best.d < __longlong_as_double(0x7FF0000000000000LL);
-        int f = __popcll(__ballot(has));
-        if (f > KNN_K) f = KNN_K;
+        double r;
+        int f = knn_query(st, buf, m, p, r);
+        wave_lds_fence();
+        Best b;
+        b.d = __longlong_as_double(0x7FF0000000000000LL); b.o = 0xFFFFFFFFu; b.i = 0;
+        if (lane < f) {
+            b.d = __longlong_as_double((long long)buf->d[lane]);
+            b.i = buf->i[lane];
+            b.o = __float_as_uint(m.pos4[b.i].w);
+        }
+        bitonic_sort_asc(b, lane);
         if (lane < KNN_K) {
             bool ok = lane < f;
-            idx[s * KNN_K + lane] = ok ? (int32_t)st.best.o : -1;
-            d2[s * KNN_K + lane] = ok ? st.best.d : 0.0;
+            idx[s * KNN_K + lane] = ok ? (int32_t)b.o : -1;
+            d2[s * KNN_K + lane] = ok ? b.d : 0.0;
         }
         if (lane == 0) found[s] = f;
+        if (work && lane == 0) { work[4 * s] = st.c_nodes; work[4 * s + 1] = st.c_leaves; work[4 * s + 2] = st.c_reduces; work[4 * s + 3] = st.c_cands; }
+        wave_lds_fence();
     }
 }
 

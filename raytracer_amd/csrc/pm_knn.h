@@ -1,10 +1,20 @@
-// pm_knn.h -- wave-per-query exact k-NN (k = 63) over a 64-ary BVH of Morton-sorted photons.
+// pm_knn.h -- wave-per-query exact k-NN (k = 63) over a 64-ary BVH of Hilbert-sorted photons.
 //
-// Replaces find_nearest_photons + insert (reference src/PhotonMap.cpp:142-255).  The reference
-// keeps a 63-entry max-heap per query; on a 64-lane wavefront the k-best list instead lives one
-// entry per lane, sorted ascending by (d2, emission index), and is maintained with wave-wide
-// insertion / bitonic networks.  Every tree node has up to 64 children, so one coalesced wave
-// load fetches all child boxes (or all 64 photons of a leaf) of a node.
+// Replaces find_nearest_photons + insert (reference src/PhotonMap.cpp:142-255) and the radiance
+// loops that consume their result (src/Raytrace.cpp:97-131, 136-170).
+//
+// The reference keeps a 63-entry max-heap per query.  Here one 64-lane wavefront serves one query:
+//   * every tree node has up to 64 children, so ONE coalesced wave load fetches all child boxes of a
+//     node, or all 64 photons of a leaf (one photon per lane);
+//   * photons closer than the current bound `lim` are appended, ballot-compacted, to a per-wave LDS
+//     candidate buffer (no ordering is maintained);
+//   * when the buffer holds >= 63 entries for the first time, and whenever it fills up, the exact
+//     63rd-smallest squared distance is found with a wave-wide binary radix select on the IEEE bit
+//     patterns (mostly scalar-unit work: ballots + popcounts), `lim` drops to it and the buffer is
+//     compacted to the 63 survivors;
+//   * the radiance sum is order independent: each term is truncated to a multiple of 2^-56 and summed
+//     as 64-bit integers (see the oracle, oracle/pm_oracle.c orc_gather), so no sort is needed.
+// Photons at exactly the k-th distance have weight (1 - d2/r)^2 == 0, so ties cannot change the sum.
 #pragma once
 #include "pm_device.h"
 
@@ -13,6 +23,14 @@ namespace pm {
 constexpr int KNN_K = 63;
 constexpr int MAX_LEVELS = 5;        // 64^5 photons
 constexpr double MAX_R2 = 100.0;     // MAX_PHOTON_RADIUS, reference src/Raytrace.cpp:13 (compared with squared distance)
+#ifndef PM_KBUF
+#define PM_KBUF 256
+#endif
+constexpr int KBUF = PM_KBUF;        // candidate buffer entries per wave
+#ifndef PM_REDUCE_AT
+#define PM_REDUCE_AT (PM_KBUF - 64)   // reduce the buffer to 63 entries when it reaches this (<= KBUF - 64)
+#endif
+static_assert(PM_REDUCE_AT <= KBUF - 64 && PM_REDUCE_AT >= 64, "a leaf appends up to 64 entries");
 
 struct BoxRec { float lox, loy, loz, pad0, hix, hiy, hiz, pad1; };  // 32 B
 
@@ -25,102 +43,169 @@ struct MapView {
     int cnt[MAX_LEVELS];
 };
 
-__device__ inline float wave_min_f32(float v) {
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) v = fminf(v, __shfl_xor(v, s));
-    return v;
-}
-
-struct Best {
-    double d;      // squared distance (+inf = empty)
-    uint32_t o;    // emission index (tie break)
-    uint32_t i;    // index in sorted order
+// per-wave LDS working set
+struct KnnBuf {
+    unsigned long long d[KBUF];  // squared distances as IEEE bit patterns (>= 0, so they order like integers)
+    uint32_t i[KBUF];            // photon index in sorted order
+    unsigned long long acc[4];   // fixed-point radiance accumulators (3 used)
 };
-__device__ inline bool key_less(double da, uint32_t oa, double db, uint32_t ob) { return da < db || (da == db && oa < ob); }
 
-// compare-exchange with lane^j; keepmin lanes keep the smaller key
-__device__ inline void cmpx(Best &b, int j, bool keepmin) {
-    double pd = __shfl_xor(b.d, j);
-    uint32_t po = __shfl_xor(b.o, j);
-    uint32_t pi = __shfl_xor(b.i, j);
-    bool take = keepmin ? key_less(pd, po, b.d, b.o) : key_less(b.d, b.o, pd, po);
-    if (take) { b.d = pd; b.o = po; b.i = pi; }
-}
-__device__ inline void bitonic_sort_asc(Best &b, int lane) {
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            bool up = (lane & k) == 0 || k == 64;
-            bool lower = (lane & j) == 0;
-            cmpx(b, j, lower == up);
-        }
+// ---- wave-wide reductions on the DPP network (no LDS round trips); result is wave-uniform
+#define PM_DPP_STEP(T, OP, CTRL, RM)                                                                    \
+    { int t_ = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, RM, 0xf, false); \
+      v = OP(v, __builtin_bit_cast(T, t_)); }
+__device__ inline float fmin_op(float a, float b) { return fminf(a, b); }
+__device__ inline uint32_t or_op(uint32_t a, uint32_t b) { return a | b; }
+__device__ inline uint32_t and_op(uint32_t a, uint32_t b) { return a & b; }
+#define PM_WAVE_REDUCE(NAME, T, OP)                                                     \
+    __device__ inline T NAME(T v) {                                                     \
+        PM_DPP_STEP(T, OP, 0xb1, 0xf)  /* quad_perm [1,0,3,2] */                       \
+        PM_DPP_STEP(T, OP, 0x4e, 0xf)  /* quad_perm [2,3,0,1] */                       \
+        PM_DPP_STEP(T, OP, 0x124, 0xf) /* row_ror:4 */                                 \
+        PM_DPP_STEP(T, OP, 0x128, 0xf) /* row_ror:8 */                                 \
+        PM_DPP_STEP(T, OP, 0x142, 0xa) /* row_bcast:15 -> rows 1,3 */                  \
+        PM_DPP_STEP(T, OP, 0x143, 0xc) /* row_bcast:31 -> rows 2,3 */                  \
+        return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); \
     }
+PM_WAVE_REDUCE(wave_min_f32, float, fmin_op)
+PM_WAVE_REDUCE(wave_or_u32, uint32_t, or_op)
+PM_WAVE_REDUCE(wave_and_u32, uint32_t, and_op)
+
+__device__ inline int lane_rank(unsigned long long mask) {   // set bits of mask below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
-__device__ inline void bitonic_merge_asc(Best &b, int lane) {
-#pragma unroll
-    for (int j = 32; j > 0; j >>= 1) cmpx(b, j, (lane & j) == 0);
+__device__ inline void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ inline unsigned long long readlane_u64(unsigned long long v, int l) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 struct KnnState {
-    Best best;            // this lane's entry of the sorted k-best list
-    double tau_d;         // key of entry k-1 (wave-uniform): candidates must sort before it
-    uint32_t tau_o;
+    double lim;          // wave-uniform: only photons with d2 < lim are collected (starts at MAX_R2)
+    int count;           // entries in the buffer
+    bool reduced;        // lim is an exact 63rd-smallest (some reduce has happened)
     int lane;
+    KnnBuf *buf;
+    // wave-uniform work counters (scalar registers): node visits, leaf visits, reduces, appended candidates
+    uint32_t c_nodes, c_leaves, c_reduces, c_cands;
 };
 
-__device__ inline void knn_update_tau(KnnState &st) {
-    st.tau_d = __shfl(st.best.d, KNN_K - 1);
-    st.tau_o = __shfl(st.best.o, KNN_K - 1);
+// Exact 63rd-smallest of the first `count` (>= 63) buffer entries; compacts the buffer to the 63
+// entries that matter (all with d2 < tau plus as many d2 == tau as needed) and lowers lim to tau.
+// Plain values in and out (not the state struct): the function is deliberately not inlined -- it runs
+// 2-3 times per query but would otherwise be cloned into every level of the traversal and drive its
+// register count -- and a by-reference state would be forced into scratch memory.
+__device__ __noinline__ unsigned long long knn_reduce_impl(KnnBuf *buf, int count) {
+    constexpr int NS = KBUF / 64;
+    const int lane = threadIdx.x & 63;
+    wave_lds_fence();
+    unsigned long long v[NS];
+    uint32_t idx[NS];
+    unsigned long long act[NS];
+    uint32_t o_hi = 0, o_lo = 0, a_hi = 0xFFFFFFFFu, a_lo = 0xFFFFFFFFu;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        bool valid = lane + 64 * s < count;
+        v[s] = 0ULL; idx[s] = 0u; act[s] = 0ULL;
+        if (64 * s >= count) continue;   // wave-uniform: unused slots cost nothing below either
+        v[s] = valid ? buf->d[lane + 64 * s] : 0ULL;
+        idx[s] = valid ? buf->i[lane + 64 * s] : 0u;
+        act[s] = __ballot(valid);
+        if (valid) { o_hi |= (uint32_t)(v[s] >> 32); o_lo |= (uint32_t)v[s]; a_hi &= (uint32_t)(v[s] >> 32); a_lo &= (uint32_t)v[s]; }
+    }
+    // bits above the first differing one are common to all entries: skip them
+    unsigned long long diff = (((unsigned long long)(wave_or_u32(o_hi) ^ wave_and_u32(a_hi))) << 32) | (wave_or_u32(o_lo) ^ wave_and_u32(a_lo));
+    int need = KNN_K, remaining = count;
+    if (diff != 0ULL) {
+        for (int b = 63 - __clzll((long long)diff); b >= 0 && remaining > 1; b--) {
+            uint32_t bit = 1u << (b & 31);
+            unsigned long long z[NS];
+            int zero_cnt = 0;
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                z[s] = 0ULL;
+                if (act[s] == 0ULL) continue;
+                uint32_t w = b >= 32 ? (uint32_t)(v[s] >> 32) : (uint32_t)v[s];
+                z[s] = __ballot((w & bit) == 0u) & act[s];
+                zero_cnt += __popcll(z[s]);
+            }
+            if (need <= zero_cnt) {
+#pragma unroll
+                for (int s = 0; s < NS; s++) act[s] = z[s];
+                remaining = zero_cnt;
+            } else {
+                need -= zero_cnt;
+#pragma unroll
+                for (int s = 0; s < NS; s++) act[s] &= ~z[s];
+                remaining -= zero_cnt;
+            }
+        }
+    }
+    // every still-active entry equals the answer
+    unsigned long long tau = 0ULL;
+#pragma unroll
+    for (int s = NS - 1; s >= 0; s--)
+        if (act[s]) tau = readlane_u64(v[s], __ffsll((long long)act[s]) - 1);
+    // compact: all entries < tau, then enough entries == tau to make 63
+    unsigned long long lt[NS], eq[NS];
+    int n_lt = 0;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        bool valid = lane + 64 * s < count;
+        lt[s] = eq[s] = 0ULL;
+        if (64 * s >= count) continue;
+        lt[s] = __ballot(valid && v[s] < tau);
+        eq[s] = __ballot(valid && v[s] == tau);
+        n_lt += __popcll(lt[s]);
+    }
+    int run_lt = 0, run_eq = 0;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        bool valid = lane + 64 * s < count;
+        if (64 * s >= count) continue;
+        int pos = -1;
+        if (valid && v[s] < tau) pos = run_lt + lane_rank(lt[s]);
+        else if (valid && v[s] == tau) { int e = n_lt + run_eq + lane_rank(eq[s]); if (e < KNN_K) pos = e; }
+        if (pos >= 0) { buf->d[pos] = v[s]; buf->i[pos] = idx[s]; }
+        run_lt += __popcll(lt[s]);
+        run_eq += __popcll(eq[s]);
+    }
+    wave_lds_fence();
+    return tau;
 }
-
-#ifndef PM_INSERT_MAX
-#define PM_INSERT_MAX 6
-#endif
+__device__ inline void knn_reduce(KnnState &st) {
+    st.c_reduces++;
+    unsigned long long tau = knn_reduce_impl(st.buf, st.count);
+    st.count = KNN_K;
+    st.lim = __longlong_as_double((long long)tau);
+    st.reduced = true;
+}
 
 // offer the (up to) 64 photons of one leaf
 __device__ inline void knn_leaf(KnnState &st, const MapView &m, const V3 &q, int leaf) {
     long long i = (long long)leaf * 64 + st.lane;
     bool valid = i < m.n;
+    st.c_leaves++;
     float4 p = valid ? m.pos4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     // find_nearest_photons, src/PhotonMap.cpp:211-214
     double dx = (double)p.x - q.x, dy = (double)p.y - q.y, dz = (double)p.z - q.z;
     double d2 = dx * dx + dy * dy + dz * dz;
-    uint32_t o = __float_as_uint(p.w);
-    bool pass = valid && d2 < MAX_R2 && key_less(d2, o, st.tau_d, st.tau_o);
+    bool pass = valid && d2 < st.lim;
     unsigned long long mask = __ballot(pass);
     if (mask == 0ULL) return;
-    Best c;
-    c.d = pass ? d2 : __longlong_as_double(0x7FF0000000000000LL);
-    c.o = pass ? o : 0xFFFFFFFFu;
-    c.i = (uint32_t)i;
-    if (__popcll(mask) <= PM_INSERT_MAX) {
-        // few survivors: wave-wide insertion, one candidate at a time
-        while (mask) {
-            int src = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            double cd = __shfl(c.d, src);
-            uint32_t co = __shfl(c.o, src), ci = __shfl(c.i, src);
-            // tau may have tightened since the ballot
-            if (!key_less(cd, co, st.tau_d, st.tau_o)) continue;
-            bool before = key_less(st.best.d, st.best.o, cd, co);
-            int pos = __popcll(__ballot(before));
-            double pd = __shfl_up(st.best.d, 1);
-            uint32_t po = __shfl_up(st.best.o, 1), pi = __shfl_up(st.best.i, 1);
-            if (st.lane > pos) { st.best.d = pd; st.best.o = po; st.best.i = pi; }
-            else if (st.lane == pos) { st.best.d = cd; st.best.o = co; st.best.i = ci; }
-            knn_update_tau(st);
-        }
-    } else {
-        // many survivors: sort them, keep the 64 smallest of the union, re-sort
-        bitonic_sort_asc(c, st.lane);
-        int rev = 63 - st.lane;
-        double rd = __shfl(c.d, rev);
-        uint32_t ro = __shfl(c.o, rev), ri = __shfl(c.i, rev);
-        if (key_less(rd, ro, st.best.d, st.best.o)) { st.best.d = rd; st.best.o = ro; st.best.i = ri; }
-        bitonic_merge_asc(st.best, st.lane);
-        knn_update_tau(st);
+    if (pass) {
+        int pos = st.count + lane_rank(mask);
+        st.buf->d[pos] = (unsigned long long)__double_as_longlong(d2);
+        st.buf->i[pos] = (uint32_t)i;
     }
+    int np = __popcll(mask);
+    st.count += np;
+    st.c_cands += np;
+    if (st.count >= PM_REDUCE_AT) knn_reduce(st);
 }
 
 // squared distance from q to a box, rounded so that it never exceeds the d2 of a photon inside it
@@ -131,41 +216,65 @@ __device__ inline double box_d2(const BoxRec &b, const V3 &q) {
     return gx * gx + gy * gy + gz * gz;
 }
 
-// visit the children of `node` at level LV+1 (they live in m.lv[LV]); nearest child first
+// largest squared distance from q to a point of the box: never below the d2 of a photon inside it
+__device__ inline double box_dmax2(const BoxRec &b, const V3 &q) {
+    double fx = fmax(fabs((double)b.lox - q.x), fabs((double)b.hix - q.x));
+    double fy = fmax(fabs((double)b.loy - q.y), fabs((double)b.hiy - q.y));
+    double fz = fmax(fabs((double)b.loz - q.z), fabs((double)b.hiz - q.z));
+    return fx * fx + fy * fy + fz * fz;
+}
+
+// visit the children of `node` at level LV+1 (they live in m.lv[LV]).  A child that is full (>= 63
+// photons below it) bounds the k-th distance by its farthest corner, so `lim` tightens before any
+// photon is read; the child with the smallest such bound goes first, the rest in lane order.
 template <int LV>
 __device__ inline void knn_visit(KnnState &st, const MapView &m, const V3 &q, int node) {
     const float INF = __int_as_float(0x7F800000);
     long long c0 = (long long)node * 64;
     long long ci = c0 + st.lane;
+    st.c_nodes++;
     double dm = __longlong_as_double(0x7FF0000000000000LL);
+    float fmax2 = INF;
     if (ci < (long long)m.cnt[LV]) {
         const float4 *bp = reinterpret_cast<const float4 *>(&m.lv[LV][ci]);
         float4 lo = bp[0], hi = bp[1];
         BoxRec b = {lo.x, lo.y, lo.z, 0.f, hi.x, hi.y, hi.z, 0.f};
         dm = box_d2(b, q);
+        // every node but the last of its level is full (64^(LV+1) >= 63 photons)
+        if (ci + 1 < (long long)m.cnt[LV]) fmax2 = __double2float_ru(box_dmax2(b, q));
     }
-    float key = (dm < MAX_R2) ? (float)dm : INF;
+    float best_max = wave_min_f32(fmax2);
+    int first_c = -1;
+    if (best_max < INF) {
+        // >= 63 photons lie within best_max: collect d2 <= best_max (one double ulp above, since the test is '<')
+        double bound = __longlong_as_double(__double_as_longlong((double)best_max) + 1);
+        if (bound < st.lim) { st.lim = bound; st.reduced = false; }   // lim is a bound again, not an exact k-th distance
+        first_c = __ffsll((long long)__ballot(fmax2 == best_max)) - 1;
+    }
+    bool todo = true;
     for (;;) {
-        if (!(dm <= st.tau_d)) key = INF;   // pruned by the current k-th distance (ties stay: index tie-break)
-        float mn = wave_min_f32(key);
-        if (mn == INF) break;
-        unsigned long long eq = __ballot(key == mn);
-        int c = __ffsll((long long)eq) - 1;
-        if (st.lane == c) key = INF;
+        bool alive = todo && dm < st.lim;
+        unsigned long long mask = __ballot(alive);
+        if (mask == 0ULL) break;
+        int c = __ffsll((long long)mask) - 1;
+        if (first_c >= 0) { if ((mask >> first_c) & 1ULL) c = first_c; first_c = -1; }
+        if (st.lane == c) todo = false;
         if constexpr (LV == 0) knn_leaf(st, m, q, (int)(c0 + c));
         else knn_visit<LV - 1>(st, m, q, (int)(c0 + c));
     }
 }
 
-// full query; on return st.best holds the sorted result list (entries >= found are +inf)
-__device__ inline void knn_query(KnnState &st, const MapView &m, const V3 &q) {
+// Full query.  On return the buffer holds `found` = min(#photons with d2 < 100, 63) entries in lanes'
+// slots 0..found-1 (unordered) and r is the largest of their d2 (the reference's distances[0]).
+__device__ inline int knn_query(KnnState &st, KnnBuf *buf, const MapView &m, const V3 &q, double &r) {
     st.lane = threadIdx.x & 63;
-    st.best.d = __longlong_as_double(0x7FF0000000000000LL);
-    st.best.o = 0xFFFFFFFFu;
-    st.best.i = 0;
-    st.tau_d = st.best.d;
-    st.tau_o = 0xFFFFFFFFu;
-    if (m.n <= 0) return;
+    st.buf = buf;
+    st.lim = MAX_R2;
+    st.count = 0;
+    st.reduced = false;
+    st.c_nodes = st.c_leaves = st.c_reduces = st.c_cands = 0;
+    r = 0.0;
+    if (m.n <= 0) return 0;
     switch (m.top) {
     case 0: knn_visit<0>(st, m, q, 0); break;
     case 1: knn_visit<1>(st, m, q, 0); break;
@@ -173,6 +282,16 @@ __device__ inline void knn_query(KnnState &st, const MapView &m, const V3 &q) {
     case 3: knn_visit<3>(st, m, q, 0); break;
     default: knn_visit<4>(st, m, q, 0); break;
     }
+    if (st.count > KNN_K) knn_reduce(st);
+    if (st.count == 0) return 0;
+    if (st.reduced) { r = st.lim; return st.count; }   // count == 63 and the largest entry is lim itself
+    // fewer than 63 photons within the radius: r = max of what was found (rare: tiny maps)
+    wave_lds_fence();
+    double d = st.lane < st.count ? __longlong_as_double((long long)st.buf->d[st.lane]) : 0.0;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) d = fmax(d, __shfl_xor(d, s));
+    r = d;
+    return st.count;
 }
 
 // One photon's term of the radiance sums: src/Raytrace.cpp:100-125 (global), :139-164 (caustic)
@@ -205,32 +324,60 @@ __device__ inline void photon_term(const float4 &pp, const uint4 &rr, const V3 &
     }
 }
 
-__device__ inline double wave_tree_sum(double v) {
-    // canonical summation order: xor-butterfly over the 64 sorted slots (same tree in the oracle)
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) v = v + __shfl_xor(v, s);
-    return v;
-}
+constexpr double FX_SCALE = 72057594037927936.0;   // 2^56
 
 // query + radiance estimate; result valid in every lane
 template <int KIND>
-__device__ inline void knn_gather(const MapView &m, const V3 &p, const V3 &nrm, double &R, double &G, double &B) {
+__device__ inline void knn_gather(KnnBuf *buf, const MapView &m, const V3 &p, const V3 &nrm, double &R, double &G, double &B) {
     KnnState st;
-    knn_query(st, m, p);
-    int found = __popcll(__ballot(st.best.d < __longlong_as_double(0x7FF0000000000000LL)));
-    int nsel = found < KNN_K ? found : KNN_K;
+    double r;
+    int found = knn_query(st, buf, m, p, r);
     R = G = B = 0.0;
-    if (nsel == 0) return;
-    double r = __shfl(st.best.d, nsel - 1);   // distances[0] of the reference's max-heap
-    double tr = 0, tg = 0, tb = 0;
-    if (st.lane < nsel) {
-        float4 pp = m.pos4[st.best.i];
-        uint4 rr = m.rest[st.best.i];
-        photon_term<KIND>(pp, rr, p, nrm, st.best.d, r, tr, tg, tb);
+    if (found == 0) return;
+    if (st.lane < 3) buf->acc[st.lane] = 0ULL;
+    wave_lds_fence();
+    if (st.lane < found) {
+        double d2 = __longlong_as_double((long long)buf->d[st.lane]);
+        if (d2 < r) {   // d2 == r has weight 0
+            uint32_t i = buf->i[st.lane];
+            float4 pp = m.pos4[i];
+            uint4 rr = m.rest[i];
+            double tr, tg, tb;
+            photon_term<KIND>(pp, rr, p, nrm, d2, r, tr, tg, tb);
+            // order-independent sum: 64-bit fixed point, 2^-56 resolution (0 <= term <= 1, <= 63 terms)
+            if (tr != 0.0) atomicAdd(&buf->acc[0], (unsigned long long)(long long)(tr * FX_SCALE));
+            if (tg != 0.0) atomicAdd(&buf->acc[1], (unsigned long long)(long long)(tg * FX_SCALE));
+            if (tb != 0.0) atomicAdd(&buf->acc[2], (unsigned long long)(long long)(tb * FX_SCALE));
+        }
     }
-    tr = wave_tree_sum(tr); tg = wave_tree_sum(tg); tb = wave_tree_sum(tb);
+    wave_lds_fence();
     const double norm_k = KIND == 0 ? (3.141592653589 * 2) : (3.141592653589 * 8);
-    R = tr / (norm_k * r); G = tg / (norm_k * r); B = tb / (norm_k * r);
+    R = ((double)(long long)buf->acc[0] * (1.0 / FX_SCALE)) / (norm_k * r);
+    G = ((double)(long long)buf->acc[1] * (1.0 / FX_SCALE)) / (norm_k * r);
+    B = ((double)(long long)buf->acc[2] * (1.0 / FX_SCALE)) / (norm_k * r);
+    wave_lds_fence();
+}
+
+// ---- sorted output for the pm_knn_query entry point only: ascending (d2, emission index)
+struct Best { double d; uint32_t o; uint32_t i; };
+__device__ inline bool key_less(double da, uint32_t oa, double db, uint32_t ob) { return da < db || (da == db && oa < ob); }
+__device__ inline void cmpx(Best &b, int j, bool keepmin) {
+    double pd = __shfl_xor(b.d, j);
+    uint32_t po = __shfl_xor(b.o, j);
+    uint32_t pi = __shfl_xor(b.i, j);
+    bool take = keepmin ? key_less(pd, po, b.d, b.o) : key_less(b.d, b.o, pd, po);
+    if (take) { b.d = pd; b.o = po; b.i = pi; }
+}
+__device__ inline void bitonic_sort_asc(Best &b, int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            bool up = (lane & k) == 0 || k == 64;
+            bool lower = (lane & j) == 0;
+            cmpx(b, j, lower == up);
+        }
+    }
 }
 
 }  // namespace pm

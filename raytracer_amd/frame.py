@@ -1,0 +1,159 @@
+"""Frame orchestration above the C-ABI: the host-side mirror of renderScene (reference
+src/Raytrace.cpp:301-343) for one process per GPU.
+
+Sharding: emission attempts are split into contiguous per-rank ranges and the
+per-rank photon shards are combined with ONE all-gather (RCCL over xGMI when the process group is
+NCCL); every rank then builds the same full map ("first n successes in global attempt order", so the
+map does not depend on the number of GPUs).  Image rows are split into interleaved 16-row blocks;
+row blocks are gathered to rank 0.  With world == 1 no collective is issued.
+
+The compute is injected (``emit_fn`` etc.) so that the sharding logic can be exercised on CPU with the
+gloo backend in tests; the product wiring (``GpuFrame``) always calls the HIP library.
+"""
+import math
+
+import numpy as np
+
+ROW_BLOCK = 16
+YIELD_EST = {0: 0.60, 1: 0.36}   # stored photons per emission attempt, default scene (global / caustic)
+
+
+def attempt_ranges(begin, total, world):
+    """Contiguous per-rank attempt ranges covering [begin, begin + per*world): [(b0, per), ...]."""
+    per = (total + world - 1) // world
+    return [(begin + r * per, per) for r in range(world)]
+
+
+def batch_attempts(want, kind, world):
+    return int(want / YIELD_EST[kind]) + 4096 * world
+
+
+def owned_row_blocks(height, rank, world):
+    nblk = (height + ROW_BLOCK - 1) // ROW_BLOCK
+    return list(range(rank, nblk, world))
+
+
+def emit_sharded(n, kind, world, rank, emit_fn, allgather_fn):
+    """First ``n`` stored photons in global attempt order.
+
+    emit_fn(begin, count) -> records of this rank's range in attempt order (array-like, rows = photons).
+    allgather_fn(records) -> list of the per-rank record arrays, in rank order.
+    Returns (list of record chunks in final order, attempts issued).
+    """
+    chunks, have, next_attempt = [], 0, 0
+    empty_rounds = 0
+    while have < n:
+        want = n - have
+        ranges = attempt_ranges(next_attempt, batch_attempts(want, kind, world), world)
+        mine = emit_fn(*ranges[rank])
+        shards = allgather_fn(mine)
+        got = 0
+        for s in shards:                       # rank order == attempt order
+            take = min(len(s), n - have)
+            if take > 0:
+                chunks.append(s[:take])
+                have += take
+                got += take
+        next_attempt = ranges[-1][0] + ranges[-1][1]
+        empty_rounds = empty_rounds + 1 if got == 0 else 0
+        if empty_rounds > 8:
+            raise RuntimeError("no emission attempt stores a photon in this scene")
+    return chunks, next_attempt
+
+
+class GpuFrame:
+    """renderScene on one rank of a (possibly single-rank) job; all compute through the HIP library."""
+
+    def __init__(self, ctx, width, height, n_photons, seed, rank=0, world=1, dist=None,
+                 cam=(0.0, 0.0, -12.0), light_color=(0.6, 0.6, 0.6), flags=0):
+        import torch
+        self.torch, self.ctx, self.dist = torch, ctx, dist
+        self.w, self.h, self.n, self.seed = width, height, n_photons, seed
+        self.rank, self.world = rank, world
+        self.cam, self.light_color, self.flags = cam, light_color, flags
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        self.pane = torch.zeros((height, width), dtype=torch.int32, device=self.dev)
+        self.maps = [None, None]
+        self.last_stats = None
+
+    # --- photon maps: createPhotonMap / createCausticPhotonMap, src/Raytrace.cpp:314-316
+    def _emit_fn(self, kind):
+        torch = self.torch
+
+        def fn(begin, count):
+            shard = torch.empty((count, 8), dtype=torch.int32, device=self.dev)
+            got = self.ctx.emit_range(kind, self.seed, self.light_color, begin, count, shard.data_ptr(), count)
+            return shard[:got]
+        return fn
+
+    def _allgather(self, mine):
+        torch, dist = self.torch, self.dist
+        if self.world == 1:
+            return [mine]
+        cnt = torch.tensor([mine.shape[0]], dtype=torch.int64, device=self.dev)
+        cnts = [torch.empty_like(cnt) for _ in range(self.world)]
+        dist.all_gather(cnts, cnt)
+        cap = max(int(c.item()) for c in cnts)
+        pad = torch.zeros((cap, 8), dtype=torch.int32, device=self.dev)
+        pad[: mine.shape[0]] = mine
+        shards = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(shards, pad)             # the one exchange step: 32-byte photon records
+        return [s[: int(c.item())] for s, c in zip(shards, cnts)]
+
+    def build_maps(self):
+        torch = self.torch
+        for m in self.maps:
+            if m is not None:
+                m.destroy()
+        self.maps = [None, None]
+        for kind in (0, 1):
+            if self.flags & (1 << kind):
+                continue
+            if self.world == 1:
+                self.maps[kind] = self.ctx.create_map(kind, self.n, self.seed, self.light_color)
+            else:
+                chunks, _ = emit_sharded(self.n, kind, self.world, self.rank, self._emit_fn(kind), self._allgather)
+                rec = torch.cat(chunks) if len(chunks) != 1 else chunks[0].contiguous()
+                self.maps[kind] = self.ctx.build_map(rec.data_ptr(), kind, n=self.n, on_device=True)
+
+    # --- the job loop + waitForCompletion, src/Raytrace.cpp:322-336
+    def render(self):
+        rp = self.ctx.params(self.w, self.h, self.seed, self.cam, self.light_color, self.flags, self.rank, self.world)
+        _, st = self.ctx.render(self.maps[0], self.maps[1], rp, d_pane=self.pane.data_ptr())
+        self.last_stats = st
+        return st
+
+    def gather_pane(self):
+        """Row blocks of all ranks -> rank 0's full pane (returns it on rank 0, None elsewhere)."""
+        torch, dist = self.torch, self.dist
+        if self.world == 1:
+            return self.pane
+        nblk = (self.h + ROW_BLOCK - 1) // ROW_BLOCK
+        hp = nblk * ROW_BLOCK
+        per = (nblk + self.world - 1) // self.world
+        mine = torch.zeros((per, ROW_BLOCK, self.w), dtype=torch.int32, device=self.dev)
+        padded = self.pane if hp == self.h else torch.cat([self.pane, torch.zeros((hp - self.h, self.w), dtype=torch.int32, device=self.dev)])
+        own = padded.view(nblk, ROW_BLOCK, self.w)[self.rank::self.world]
+        mine[: own.shape[0]] = own
+        parts = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == 0 else None
+        dist.gather(mine, parts, dst=0)
+        if self.rank != 0:
+            return None
+        full = torch.zeros((nblk, ROW_BLOCK, self.w), dtype=torch.int32, device=self.dev)
+        for r in range(self.world):
+            k = len(range(r, nblk, self.world))
+            full[r::self.world] = parts[r][:k]
+        return full.view(hp, self.w)[: self.h]
+
+    def step(self):
+        """One whole frame: both photon maps, this rank's rows, pane on rank 0."""
+        self.build_maps()
+        st = self.render()
+        pane = self.gather_pane()
+        return st, pane
+
+    def close(self):
+        for m in self.maps:
+            if m is not None:
+                m.destroy()
+        self.maps = [None, None]
