@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--photons", type=int, default=1000000)
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-row-stride", type=int, default=12)
+    ap.add_argument("--cpu-row-stride", type=int, default=1)
     ap.add_argument("--cpu-cores", type=int, default=0)
     ap.add_argument("--check", action="store_true", help="compare the CPU sample rows with the GPU pane")
     args = ap.parse_args()

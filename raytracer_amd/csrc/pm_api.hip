@@ -218,7 +218,7 @@ static int build_index(pm_map *map) {
     PMCHK(map->pos4.ensure((size_t)n * 16)); PMCHK(map->rest.ensure((size_t)n * 16));
     uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
     HIPCHK(hipMemcpyAsync(ctx->bounds.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-    unsigned nbk = (unsigned)std::min<long long>((n + 255) / 256, 2048);
+    unsigned nbk = (unsigned)std::min<long long>((n + 255) / 256, 512);
     unsigned nb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_bounds, dim3(nbk), dim3(256), 0, ctx->stream, rec, n, ctx->bounds.as<uint32_t>());
     hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, ctx->stream, rec, n, ctx->bounds.as<uint32_t>(), ctx->keys_in.as<uint64_t>(),

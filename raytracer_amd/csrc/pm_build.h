@@ -142,8 +142,11 @@ __global__ __launch_bounds__(256) void k_emit_scatter(const pm_photon *tmp, cons
 __device__ inline uint32_t f2ord(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ inline float ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
 
-// bounds[0..2] = min xyz, bounds[3..5] = max xyz as order-preserving uints (init: 0xFFFFFFFF / 0)
+// bounds[0..2] = min xyz, bounds[3..5] = max xyz as order-preserving uints (init: 0xFFFFFFFF / 0).
+// Wave reduction, then block reduction through LDS, then six atomics per BLOCK (six addresses shared by
+// every wave of the grid would serialise at the memory side).
 __global__ __launch_bounds__(256) void k_bounds(const pm_photon *ph, long long n, uint32_t *bounds) {
+    __shared__ uint32_t part[4][6];
     uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0, 0, 0};
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         uint32_t v[3] = {f2ord(ph[i].x), f2ord(ph[i].y), f2ord(ph[i].z)};
@@ -151,7 +154,13 @@ __global__ __launch_bounds__(256) void k_bounds(const pm_photon *ph, long long n
     }
     for (int a = 0; a < 3; a++) {
         for (int s = 1; s < 64; s <<= 1) { mn[a] = min(mn[a], (uint32_t)__shfl_xor((int)mn[a], s)); mx[a] = max(mx[a], (uint32_t)__shfl_xor((int)mx[a], s)); }
-        if ((threadIdx.x & 63) == 0) { atomicMin(&bounds[a], mn[a]); atomicMax(&bounds[3 + a], mx[a]); }
+        if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][a] = mn[a]; part[threadIdx.x >> 6][3 + a] = mx[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        uint32_t v = part[0][threadIdx.x];
+        for (int w = 1; w < 4; w++) v = threadIdx.x < 3 ? min(v, part[w][threadIdx.x]) : max(v, part[w][threadIdx.x]);
+        if (threadIdx.x < 3) atomicMin(&bounds[threadIdx.x], v); else atomicMax(&bounds[threadIdx.x], v);
     }
 }
 

@@ -13,7 +13,7 @@
 //     patterns (mostly scalar-unit work: ballots + popcounts), `lim` drops to it and the buffer is
 //     compacted to the 63 survivors;
 //   * the radiance sum is order independent: each term is truncated to a multiple of 2^-56 and summed
-//     as 64-bit integers (see the oracle, oracle/pm_oracle.c orc_gather), so no sort is needed.
+//     as 64-bit integers (the canonical sum defined in DESIGN.md), so no sort is needed.
 // Photons at exactly the k-th distance have weight (1 - d2/r)^2 == 0, so ties cannot change the sum.
 #pragma once
 #include "pm_device.h"
@@ -28,9 +28,15 @@ constexpr double MAX_R2 = 100.0;     // MAX_PHOTON_RADIUS, reference src/Raytrac
 #endif
 constexpr int KBUF = PM_KBUF;        // candidate buffer entries per wave
 #ifndef PM_REDUCE_AT
-#define PM_REDUCE_AT (PM_KBUF - 64)   // reduce the buffer to 63 entries when it reaches this (<= KBUF - 64)
+#define PM_REDUCE_AT 128             // reduce the buffer to 63 entries when it reaches this (<= KBUF - 64)
 #endif
-static_assert(PM_REDUCE_AT <= KBUF - 64 && PM_REDUCE_AT >= 64, "a leaf appends up to 64 entries");
+#ifndef PM_NEAREST_ALWAYS
+#define PM_NEAREST_ALWAYS 1
+#endif
+#ifndef PM_FIRST_REDUCE_AT
+#define PM_FIRST_REDUCE_AT 128
+#endif
+static_assert(PM_REDUCE_AT <= KBUF - 64 && PM_REDUCE_AT > 63, "a leaf appends up to 64 entries");
 
 struct BoxRec { float lox, loy, loz, pad0, hix, hiy, hiz, pad1; };  // 32 B
 
@@ -87,7 +93,8 @@ __device__ inline unsigned long long readlane_u64(unsigned long long v, int l) {
 struct KnnState {
     double lim;          // wave-uniform: only photons with d2 < lim are collected (starts at MAX_R2)
     int count;           // entries in the buffer
-    bool reduced;        // lim is an exact 63rd-smallest (some reduce has happened)
+    bool reduced;        // lim is an exact 63rd-smallest (set by a reduce, cleared when a box bound lowers lim)
+    bool any_reduce;     // some reduce has happened: lim is tight from here on
     int lane;
     KnnBuf *buf;
     // wave-uniform work counters (scalar registers): node visits, leaf visits, reduces, appended candidates
@@ -183,6 +190,7 @@ __device__ inline void knn_reduce(KnnState &st) {
     st.count = KNN_K;
     st.lim = __longlong_as_double((long long)tau);
     st.reduced = true;
+    st.any_reduce = true;
 }
 
 // offer the (up to) 64 photons of one leaf
@@ -205,7 +213,8 @@ __device__ inline void knn_leaf(KnnState &st, const MapView &m, const V3 &q, int
     int np = __popcll(mask);
     st.count += np;
     st.c_cands += np;
-    if (st.count >= PM_REDUCE_AT) knn_reduce(st);
+    // the first reduce comes early (after the nearest leaves) so that lim gets tight; later ones only when the buffer fills
+    if (st.count >= (st.any_reduce ? PM_REDUCE_AT : PM_FIRST_REDUCE_AT)) knn_reduce(st);
 }
 
 // squared distance from q to a box, rounded so that it never exceeds the d2 of a photon inside it
@@ -258,6 +267,11 @@ __device__ inline void knn_visit(KnnState &st, const MapView &m, const V3 &q, in
         if (mask == 0ULL) break;
         int c = __ffsll((long long)mask) - 1;
         if (first_c >= 0) { if ((mask >> first_c) & 1ULL) c = first_c; first_c = -1; }
+        else if (PM_NEAREST_ALWAYS || !st.any_reduce) {   // nearest child first
+            float key = alive ? (float)dm : INF;
+            float mn = wave_min_f32(key);
+            c = __ffsll((long long)__ballot(alive && key == mn)) - 1;
+        }
         if (st.lane == c) todo = false;
         if constexpr (LV == 0) knn_leaf(st, m, q, (int)(c0 + c));
         else knn_visit<LV - 1>(st, m, q, (int)(c0 + c));
@@ -272,6 +286,7 @@ __device__ inline int knn_query(KnnState &st, KnnBuf *buf, const MapView &m, con
     st.lim = MAX_R2;
     st.count = 0;
     st.reduced = false;
+    st.any_reduce = false;
     st.c_nodes = st.c_leaves = st.c_reduces = st.c_cands = 0;
     r = 0.0;
     if (m.n <= 0) return 0;

@@ -61,6 +61,47 @@ def emit_sharded(n, kind, world, rank, emit_fn, allgather_fn):
     return chunks, next_attempt
 
 
+def allgather_records(dist, mine, world):
+    """The one exchange step of the path: per-rank photon shards ([n_r, 8] int32 rows = 32-byte records,
+    any device) -> list of all ranks' shards in rank order.  Shards are padded to the largest count."""
+    import torch
+    if world == 1:
+        return [mine]
+    cnt = torch.tensor([mine.shape[0]], dtype=torch.int64, device=mine.device)
+    cnts = [torch.empty_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt)
+    cap = max(int(c.item()) for c in cnts)
+    pad = torch.zeros((cap, 8), dtype=torch.int32, device=mine.device)
+    pad[: mine.shape[0]] = mine
+    shards = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(shards, pad)
+    return [s[: int(c.item())] for s, c in zip(shards, cnts)]
+
+
+def gather_row_blocks(dist, pane, rank, world):
+    """Interleaved 16-row blocks of every rank's [H, W] int32 pane -> the full pane on rank 0 (None elsewhere)."""
+    import torch
+    if world == 1:
+        return pane
+    h, w = pane.shape
+    nblk = (h + ROW_BLOCK - 1) // ROW_BLOCK
+    hp = nblk * ROW_BLOCK
+    per = (nblk + world - 1) // world
+    mine = torch.zeros((per, ROW_BLOCK, w), dtype=torch.int32, device=pane.device)
+    padded = pane if hp == h else torch.cat([pane, torch.zeros((hp - h, w), dtype=torch.int32, device=pane.device)])
+    own = padded.view(nblk, ROW_BLOCK, w)[rank::world]
+    mine[: own.shape[0]] = own
+    parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+    dist.gather(mine, parts, dst=0)
+    if rank != 0:
+        return None
+    full = torch.zeros((nblk, ROW_BLOCK, w), dtype=torch.int32, device=pane.device)
+    for r in range(world):
+        k = len(range(r, nblk, world))
+        full[r::world] = parts[r][:k]
+    return full.view(hp, w)[:h]
+
+
 class GpuFrame:
     """renderScene on one rank of a (possibly single-rank) job; all compute through the HIP library."""
 
@@ -87,18 +128,7 @@ class GpuFrame:
         return fn
 
     def _allgather(self, mine):
-        torch, dist = self.torch, self.dist
-        if self.world == 1:
-            return [mine]
-        cnt = torch.tensor([mine.shape[0]], dtype=torch.int64, device=self.dev)
-        cnts = [torch.empty_like(cnt) for _ in range(self.world)]
-        dist.all_gather(cnts, cnt)
-        cap = max(int(c.item()) for c in cnts)
-        pad = torch.zeros((cap, 8), dtype=torch.int32, device=self.dev)
-        pad[: mine.shape[0]] = mine
-        shards = [torch.empty_like(pad) for _ in range(self.world)]
-        dist.all_gather(shards, pad)             # the one exchange step: 32-byte photon records
-        return [s[: int(c.item())] for s, c in zip(shards, cnts)]
+        return allgather_records(self.dist, mine, self.world)
 
     def build_maps(self):
         torch = self.torch
@@ -125,25 +155,7 @@ class GpuFrame:
 
     def gather_pane(self):
         """Row blocks of all ranks -> rank 0's full pane (returns it on rank 0, None elsewhere)."""
-        torch, dist = self.torch, self.dist
-        if self.world == 1:
-            return self.pane
-        nblk = (self.h + ROW_BLOCK - 1) // ROW_BLOCK
-        hp = nblk * ROW_BLOCK
-        per = (nblk + self.world - 1) // self.world
-        mine = torch.zeros((per, ROW_BLOCK, self.w), dtype=torch.int32, device=self.dev)
-        padded = self.pane if hp == self.h else torch.cat([self.pane, torch.zeros((hp - self.h, self.w), dtype=torch.int32, device=self.dev)])
-        own = padded.view(nblk, ROW_BLOCK, self.w)[self.rank::self.world]
-        mine[: own.shape[0]] = own
-        parts = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == 0 else None
-        dist.gather(mine, parts, dst=0)
-        if self.rank != 0:
-            return None
-        full = torch.zeros((nblk, ROW_BLOCK, self.w), dtype=torch.int32, device=self.dev)
-        for r in range(self.world):
-            k = len(range(r, nblk, self.world))
-            full[r::self.world] = parts[r][:k]
-        return full.view(hp, self.w)[: self.h]
+        return gather_row_blocks(self.dist, self.pane, self.rank, self.world)
 
     def step(self):
         """One whole frame: both photon maps, this rank's rows, pane on rank 0."""
