@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--cpu-row-stride", type=int, default=1)
     ap.add_argument("--cpu-cores", type=int, default=0)
     ap.add_argument("--check", action="store_true", help="compare the CPU sample rows with the GPU pane")
+    ap.add_argument("--dump-pane", default="", help="rank 0 writes the final pane (uint32 raw) to this file")
     args = ap.parse_args()
 
     import numpy as np
@@ -82,17 +83,21 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # PM_FORCE_DIST=1 (tests): take the collective path even with one rank, to exercise RCCL on device buffers
+    use_dist = world > 1 or os.environ.get("PM_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     ctx = ra.Context(local_rank)
     ctx.upload_scene(ra.default_scene())      # the input that is resident before the timed region
     frame = GpuFrame(ctx, args.width, args.height, args.photons, args.seed, rank=rank, world=world,
-                     dist=dist if world > 1 else None)
+                     dist=dist if use_dist else None)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -117,7 +122,7 @@ def main():
     # whole-job totals
     tot = torch.tensor([dt, float(st.closest_hit_queries), float(st.shadow_queries), float(st.gathers), float(st.absorb_points),
                         phase["ms_gather_global"], phase["ms_gather_caustic"], phase["ms_total"], t_maps], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tot.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         dt = float(mx[0]); rays = float(sm[1] + sm[2]); gathers = float(sm[3]); sp_local = float(tot[4])
@@ -154,10 +159,12 @@ def main():
                 rows = slice(args.cpu_row_stride // 2, args.height, args.cpu_row_stride)
                 cb["sample_rows_bit_identical_to_gpu"] = bool(np.array_equal(gp[rows], cpane[rows]))
             out["cpu_baseline"] = cb
+        if args.dump_pane:
+            frame.step()[1].cpu().numpy().tofile(args.dump_pane)
         print(json.dumps(out), flush=True)
     frame.close()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -5,7 +5,7 @@ Sharding: emission attempts are split into contiguous per-ra
 per-rank photon shards are combined with ONE all-gather (RCCL over xGMI when the process group is
 NCCL); every rank then builds the same full map ("first n successes in global attempt order", so the
 map does not depend on the number of GPUs).  Image rows are split into interleaved 16-row blocks;
-row blocks are gathered to rank 0.  With world == 1 no collective is issued.
+row blocks are gathered to rank 0.  Without a process group (dist=None, single GPU) no collective is issued.
 
 The compute is injected (``emit_fn`` etc.) so that the sharding logic can be exercised on CPU with the
 gloo backend in tests; the product wiring (``GpuFrame``) always calls the HIP library.
@@ -65,7 +65,7 @@ def allgather_records(dist, mine, world):
     """The one exchange step of the path: per-rank photon shards ([n_r, 8] int32 rows = 32-byte records,
     any device) -> list of all ranks' shards in rank order.  Shards are padded to the largest count."""
     import torch
-    if world == 1:
+    if dist is None:
         return [mine]
     cnt = torch.tensor([mine.shape[0]], dtype=torch.int64, device=mine.device)
     cnts = [torch.empty_like(cnt) for _ in range(world)]
@@ -81,7 +81,7 @@ def allgather_records(dist, mine, world):
 def gather_row_blocks(dist, pane, rank, world):
     """Interleaved 16-row blocks of every rank's [H, W] int32 pane -> the full pane on rank 0 (None elsewhere)."""
     import torch
-    if world == 1:
+    if dist is None:
         return pane
     h, w = pane.shape
     nblk = (h + ROW_BLOCK - 1) // ROW_BLOCK
@@ -139,7 +139,7 @@ class GpuFrame:
         for kind in (0, 1):
             if self.flags & (1 << kind):
                 continue
-            if self.world == 1:
+            if self.dist is None:
                 self.maps[kind] = self.ctx.create_map(kind, self.n, self.seed, self.light_color)
             else:
                 chunks, _ = emit_sharded(self.n, kind, self.world, self.rank, self._emit_fn(kind), self._allgather)
