@@ -271,14 +271,15 @@ __global__ __launch_bounds__(256) void k_shadow(SceneView gs, FrameParams fp, SP
 template <int KIND>
 __global__ __launch_bounds__(256) void k_gather(MapView m, SPQueue q, uint32_t n_sp) {
     __shared__ KnnBuf bufs[4];
-    KnnBuf *buf = &bufs[threadIdx.x >> 6];
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler should know
+    KnnBuf *buf = &bufs[wave_in_block];
     int lane = threadIdx.x & 63;
     double *out = KIND == 0 ? q.rad_g : q.rad_c;
     // blocks b, b+8, b+16, ... share an XCD (and its L2): give each XCD one contiguous eighth of the
     // queue (= a band of the image, so a compact part of the photon map) and stride its waves over it
     uint32_t xcd = blockIdx.x & 7, nx = gridDim.x >> 3;
     uint32_t lo = (uint32_t)(((uint64_t)n_sp * xcd) >> 3), hi = (uint32_t)(((uint64_t)n_sp * (xcd + 1)) >> 3);
-    uint32_t wl = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6), wpx = nx * 4;
+    uint32_t wl = (blockIdx.x >> 3) * 4 + (uint32_t)wave_in_block, wpx = nx * 4;
     for (uint32_t s = lo + wl; s < hi; s += wpx) {
         V3 p = {q.geo[0 * (size_t)q.cap + s], q.geo[1 * (size_t)q.cap + s], q.geo[2 * (size_t)q.cap + s]};
         V3 nrm = {q.geo[3 * (size_t)q.cap + s], q.geo[4 * (size_t)q.cap + s], q.geo[5 * (size_t)q.cap + s]};
@@ -292,11 +293,12 @@ __global__ __launch_bounds__(256) void k_gather(MapView m, SPQueue q, uint32_t n
 template <int KIND>
 __global__ __launch_bounds__(256) void k_gather_points(MapView m, const double *pts, const double *nrms, double *rad, long long count) {
     __shared__ KnnBuf bufs[4];
-    KnnBuf *buf = &bufs[threadIdx.x >> 6];
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    KnnBuf *buf = &bufs[wave_in_block];
     int lane = threadIdx.x & 63;
     long long xcd = blockIdx.x & 7, nx = gridDim.x >> 3;
     long long lo = (count * xcd) >> 3, hi = (count * (xcd + 1)) >> 3;
-    long long wl = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6), wpx = nx * 4;
+    long long wl = (blockIdx.x >> 3) * 4 + wave_in_block, wpx = nx * 4;
     for (long long s = lo + wl; s < hi; s += wpx) {
         V3 p = {pts[3 * s], pts[3 * s + 1], pts[3 * s + 2]};
         V3 nrm = {nrms[3 * s], nrms[3 * s + 1], nrms[3 * s + 2]};
@@ -309,14 +311,23 @@ __global__ __launch_bounds__(256) void k_gather_points(MapView m, const double *
 // raw k-NN (pm_knn_query): idx = emission index, ascending (d2, idx)
 __global__ __launch_bounds__(256) void k_knn_query(MapView m, const double *pts, long long count, int32_t *idx, double *d2, int32_t *found, uint32_t *work) {
     __shared__ KnnBuf bufs[4];
-    KnnBuf *buf = &bufs[threadIdx.x >> 6];
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    KnnBuf *buf = &bufs[wave_in_block];
     int lane = threadIdx.x & 63;
-    long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves_total = ((long long)gridDim.x * blockDim.x) >> 6;
+    long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + wave_in_block, waves_total = ((long long)gridDim.x * blockDim.x) >> 6;
     for (long long s = wave; s < count; s += waves_total) {
         V3 p = {pts[3 * s], pts[3 * s + 1], pts[3 * s + 2]};
         KnnState st;
         double r;
+#ifdef PM_STAMPS
+        unsigned long long tq0 = __builtin_amdgcn_s_memtime();
+#endif
         int f = knn_query(st, buf, m, p, r);
+#ifdef PM_STAMPS
+        // diagnostic build: the four work words carry cycles (total, node sections, leaf sections, reduces) instead
+        unsigned long long tq1 = __builtin_amdgcn_s_memtime();
+        st.c_nodes = (uint32_t)(tq1 - tq0); st.c_leaves = (uint32_t)st.t_node; st.c_reduces = (uint32_t)st.t_leaf; st.c_cands = (uint32_t)st.t_red;
+#endif
         wave_lds_fence();
         Best b;
         b.d = __longlong_as_double(0x7FF0000000000000LL); b.o = 0xFFFFFFFFu; b.i = 0;

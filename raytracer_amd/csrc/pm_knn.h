@@ -54,6 +54,7 @@ struct KnnBuf {
     unsigned long long d[KBUF];  // squared distances as IEEE bit patterns (>= 0, so they order like integers)
     uint32_t i[KBUF];            // photon index in sorted order
     unsigned long long acc[4];   // fixed-point radiance accumulators (3 used)
+    uint32_t hist[64];           // d2 histogram of the select
 };
 
 // ---- wave-wide reductions on the DPP network (no LDS round trips); result is wave-uniform
@@ -99,34 +100,89 @@ struct KnnState {
     KnnBuf *buf;
     // wave-uniform work counters (scalar registers): node visits, leaf visits, reduces, appended candidates
     uint32_t c_nodes, c_leaves, c_reduces, c_cands;
+#ifdef PM_STAMPS
+    unsigned long long t_node, t_leaf, t_red;   // diagnostic build only: shader cycles per section
+#endif
 };
+#ifdef PM_STAMPS
+#define PM_T0 unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+#define PM_T1(field) st.field += __builtin_amdgcn_s_memtime() - t0_;
+#else
+#define PM_T0
+#define PM_T1(field)
+#endif
 
 // Exact 63rd-smallest of the first `count` (>= 63) buffer entries; compacts the buffer to the 63
 // entries that matter (all with d2 < tau plus as many d2 == tau as needed) and lowers lim to tau.
 // Plain values in and out (not the state struct): the function is deliberately not inlined -- it runs
 // 2-3 times per query but would otherwise be cloned into every level of the traversal and drive its
 // register count -- and a by-reference state would be forced into scratch memory.
-__device__ __noinline__ unsigned long long knn_reduce_impl(KnnBuf *buf, int count) {
+__device__ inline uint32_t wave_scan_incl_u32(uint32_t x) {   // inclusive prefix sum over the 64 lanes (DPP)
+    uint32_t r = x;
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x113, 0xf, 0xf, false);   // row_shr:3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x114, 0xf, 0xe, false);   // row_shr:4, banks 1-3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x118, 0xf, 0xc, false);   // row_shr:8, banks 2-3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+    return r;
+}
+
+__device__ __noinline__ unsigned long long knn_reduce_impl(KnnBuf *buf_in, int count_in, int lim_lo_in, int lim_hi_in) {
     constexpr int NS = KBUF / 64;
     const int lane = threadIdx.x & 63;
+    // arguments of a real call arrive in vector registers; all are wave-uniform, and saying so keeps the
+    // whole select (masks, counters, loop control) on the scalar unit
+    const int count = __builtin_amdgcn_readfirstlane(count_in);
+    const double lim = __hiloint2double(__builtin_amdgcn_readfirstlane(lim_hi_in), __builtin_amdgcn_readfirstlane(lim_lo_in));
+    // the buffer lives in LDS: the low 32 bits of its generic address are the LDS offset; going back to an
+    // LDS-qualified pointer turns the flat loads/stores of this out-of-line function into ds_read / ds_write
+    typedef __attribute__((address_space(3))) KnnBuf LdsKnnBuf;
+    LdsKnnBuf *buf = (LdsKnnBuf *)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(unsigned long long)buf_in);
+    buf->hist[lane] = 0u;
     wave_lds_fence();
     unsigned long long v[NS];
-    uint32_t idx[NS];
+    uint32_t idx[NS], bin[NS];
     unsigned long long act[NS];
-    uint32_t o_hi = 0, o_lo = 0, a_hi = 0xFFFFFFFFu, a_lo = 0xFFFFFFFFu;
+    // Stage 1: 64-bin histogram of d2 over [0, lim).  The bin is a monotone function of d2, so the bin in
+    // which the running count crosses 63 holds the answer and only its few entries need an exact select.
+    // (Photons spread evenly over a surface make d2 itself uniform, so the bins fill evenly.)
+    const double scale = (double)(64.0f * __frcp_rn((float)lim));
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         bool valid = lane + 64 * s < count;
-        v[s] = 0ULL; idx[s] = 0u; act[s] = 0ULL;
+        v[s] = 0ULL; idx[s] = 0u; act[s] = 0ULL; bin[s] = 0u;
         if (64 * s >= count) continue;   // wave-uniform: unused slots cost nothing below either
         v[s] = valid ? buf->d[lane + 64 * s] : 0ULL;
         idx[s] = valid ? buf->i[lane + 64 * s] : 0u;
-        act[s] = __ballot(valid);
-        if (valid) { o_hi |= (uint32_t)(v[s] >> 32); o_lo |= (uint32_t)v[s]; a_hi &= (uint32_t)(v[s] >> 32); a_lo &= (uint32_t)v[s]; }
+        if (valid) {
+            bin[s] = (uint32_t)fmin(__longlong_as_double((long long)v[s]) * scale, 63.0);
+            atomicAdd((uint32_t *)&buf->hist[bin[s]], 1u);
+        }
     }
-    // bits above the first differing one are common to all entries: skip them
-    unsigned long long diff = (((unsigned long long)(wave_or_u32(o_hi) ^ wave_and_u32(a_hi))) << 32) | (wave_or_u32(o_lo) ^ wave_and_u32(a_lo));
-    int need = KNN_K, remaining = count;
+    wave_lds_fence();
+    uint32_t h = buf->hist[lane];
+    uint32_t inc = wave_scan_incl_u32(h);
+    int bstar = __ffsll((long long)__ballot(inc >= (uint32_t)KNN_K)) - 1;   // exists: count >= 63
+    int need = KNN_K - (int)((uint32_t)__builtin_amdgcn_readlane((int)inc, bstar) - (uint32_t)__builtin_amdgcn_readlane((int)h, bstar));
+    int remaining = 0;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        if (64 * s >= count) continue;
+        act[s] = __ballot(lane + 64 * s < count && bin[s] == (uint32_t)bstar);
+        remaining += __popcll(act[s]);
+    }
+    // Stage 2: exact select of the need-th smallest among the entries of that bin: binary radix select on the
+    // IEEE bit patterns (ballots + scalar popcounts), common leading bits skipped.
+    uint32_t o_hi = 0, o_lo = 0, a_hi = 0xFFFFFFFFu, a_lo = 0xFFFFFFFFu;
+    unsigned long long diff = 0ULL;
+    if (remaining > 1) {
+#pragma unroll
+        for (int s = 0; s < NS; s++)
+            if ((act[s] >> lane) & 1ULL) { o_hi |= (uint32_t)(v[s] >> 32); o_lo |= (uint32_t)v[s]; a_hi &= (uint32_t)(v[s] >> 32); a_lo &= (uint32_t)v[s]; }
+        diff = (((unsigned long long)(wave_or_u32(o_hi) ^ wave_and_u32(a_hi))) << 32) | (wave_or_u32(o_lo) ^ wave_and_u32(a_lo));
+    }
     if (diff != 0ULL) {
         for (int b = 63 - __clzll((long long)diff); b >= 0 && remaining > 1; b--) {
             uint32_t bit = 1u << (b & 31);
@@ -185,16 +241,20 @@ __device__ __noinline__ unsigned long long knn_reduce_impl(KnnBuf *buf, int coun
     return tau;
 }
 __device__ inline void knn_reduce(KnnState &st) {
+    PM_T0
     st.c_reduces++;
-    unsigned long long tau = knn_reduce_impl(st.buf, st.count);
+    unsigned long long tau = knn_reduce_impl(st.buf, st.count, __double2loint(st.lim), __double2hiint(st.lim));
+    tau = readlane_u64(tau, 0);   // the result of a real call comes back in vector registers; it is wave-uniform
     st.count = KNN_K;
     st.lim = __longlong_as_double((long long)tau);
     st.reduced = true;
     st.any_reduce = true;
+    PM_T1(t_red)
 }
 
 // offer the (up to) 64 photons of one leaf
 __device__ inline void knn_leaf(KnnState &st, const MapView &m, const V3 &q, int leaf) {
+    PM_T0
     long long i = (long long)leaf * 64 + st.lane;
     bool valid = i < m.n;
     st.c_leaves++;
@@ -204,7 +264,7 @@ __device__ inline void knn_leaf(KnnState &st, const MapView &m, const V3 &q, int
     double d2 = dx * dx + dy * dy + dz * dz;
     bool pass = valid && d2 < st.lim;
     unsigned long long mask = __ballot(pass);
-    if (mask == 0ULL) return;
+    if (mask == 0ULL) { PM_T1(t_leaf) return; }
     if (pass) {
         int pos = st.count + lane_rank(mask);
         st.buf->d[pos] = (unsigned long long)__double_as_longlong(d2);
@@ -213,6 +273,7 @@ __device__ inline void knn_leaf(KnnState &st, const MapView &m, const V3 &q, int
     int np = __popcll(mask);
     st.count += np;
     st.c_cands += np;
+    PM_T1(t_leaf)
     // the first reduce comes early (after the nearest leaves) so that lim gets tight; later ones only when the buffer fills
     if (st.count >= (st.any_reduce ? PM_REDUCE_AT : PM_FIRST_REDUCE_AT)) knn_reduce(st);
 }
@@ -239,6 +300,7 @@ __device__ inline double box_dmax2(const BoxRec &b, const V3 &q) {
 template <int LV>
 __device__ inline void knn_visit(KnnState &st, const MapView &m, const V3 &q, int node) {
     const float INF = __int_as_float(0x7F800000);
+    PM_T0
     long long c0 = (long long)node * 64;
     long long ci = c0 + st.lane;
     st.c_nodes++;
@@ -261,6 +323,7 @@ __device__ inline void knn_visit(KnnState &st, const MapView &m, const V3 &q, in
         first_c = __ffsll((long long)__ballot(fmax2 == best_max)) - 1;
     }
     bool todo = true;
+    PM_T1(t_node)
     for (;;) {
         bool alive = todo && dm < st.lim;
         unsigned long long mask = __ballot(alive);
@@ -288,6 +351,9 @@ __device__ inline int knn_query(KnnState &st, KnnBuf *buf, const MapView &m, con
     st.reduced = false;
     st.any_reduce = false;
     st.c_nodes = st.c_leaves = st.c_reduces = st.c_cands = 0;
+#ifdef PM_STAMPS
+    st.t_node = st.t_leaf = st.t_red = 0;
+#endif
     r = 0.0;
     if (m.n <= 0) return 0;
     switch (m.top) {
