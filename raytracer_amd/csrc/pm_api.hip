@@ -73,7 +73,7 @@ struct pm_ctx {
 struct pm_map {
     pm_ctx *ctx = nullptr;
     long long n = 0;
-    DevBuf records, pos4, rest, boxes;
+    DevBuf records, pos4, rest, boxes, cells, keys;
     MapView view{};
 };
 
@@ -231,6 +231,22 @@ static int build_index(pm_map *map) {
                           ctx->vals_out.as<uint32_t>(), (size_t)n, ctx->stream));
     hipLaunchKernelGGL(k_permute, dim3(nb), dim3(256), 0, ctx->stream, rec, ctx->vals_out.as<uint32_t>(), n, map->pos4.as<float4>(),
                        map->rest.as<uint4>());
+    // linear octree tables
+    int lmax = 0;
+    while (lmax < 8 && (1LL << (3 * (lmax + 1))) <= 4 * n) lmax++;
+    long long ncells = cell_off(lmax + 1);
+    PMCHK(map->cells.ensure((size_t)ncells * 4));
+    PMCHK(map->keys.ensure((size_t)n * 8));
+    HIPCHK(hipMemcpyAsync(map->keys.p, ctx->keys_out.p, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_cell_tables, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, ctx->stream, ctx->keys_out.as<uint64_t>(), n,
+                       map->cells.as<uint32_t>(), lmax);
+    uint32_t hb[6];
+    HIPCHK(hipMemcpyAsync(hb, ctx->bounds.p, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    auto ord2f_host = [](uint32_t u) { uint32_t b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; memcpy(&f, &b, 4); return f; };
+    float gext = 0.f;
+    for (int a = 0; a < 3; a++) { v.glo[a] = ord2f_host(hb[a]); gext = std::max(gext, ord2f_host(hb[3 + a]) - v.glo[a]); }
+    v.gext = gext; v.gu = (double)gext / 2097152.0; v.lmax = lmax; v.cells = map->cells.as<uint32_t>(); v.keys = map->keys.as<uint64_t>();
     // level sizes
     int cnt[MAX_LEVELS];
     int top = 0;
@@ -321,7 +337,7 @@ extern "C" int pm_map_download(pm_map *map, pm_photon *host_out) {
 extern "C" int pm_map_destroy(pm_map *map) {
     if (!map) return PM_OK;
     if (map->ctx) { (void)hipSetDevice(map->ctx->device); (void)hipStreamSynchronize(map->ctx->stream); }
-    map->records.release(); map->pos4.release(); map->rest.release(); map->boxes.release();
+    map->records.release(); map->pos4.release(); map->rest.release(); map->boxes.release(); map->cells.release(); map->keys.release();
     delete map;
     return PM_OK;
 }

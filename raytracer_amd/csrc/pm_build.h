@@ -4,6 +4,7 @@
 #include "pm_device.h"
 #include "pm_knn.h"
 #include "pm_hilbert.h"
+#include "pm_grid.h"
 #include "../../include/raytracer_amd.h"
 
 namespace pm {
@@ -172,12 +173,29 @@ __global__ __launch_bounds__(256) void k_morton(const pm_photon *ph, long long n
     float ext = 0.f;
     for (int a = 0; a < 3; a++) ext = fmaxf(ext, ord2f(bounds[3 + a]) - ord2f(bounds[a]));
     uint32_t qv[3];
-    for (int a = 0; a < 3; a++) {
-        float t = ext > 0.f ? (p[a] - ord2f(bounds[a])) / ext : 0.f;
-        qv[a] = (uint32_t)fminf(fmaxf(t * 2097152.0f, 0.f), 2097151.0f);
-    }
-    keys[i] = hilbert3<21>(qv[0], qv[1], qv[2]);
+    for (int a = 0; a < 3; a++) qv[a] = quant21(p[a], ord2f(bounds[a]), ext);
+#if PM_USE_GRID
+    keys[i] = morton63(qv[0], qv[1], qv[2]);     // linear octree: aligned cells are contiguous key ranges
+#else
+    keys[i] = hilbert3<21>(qv[0], qv[1], qv[2]); // BVH over runs of 64: Hilbert runs are spatially connected
+#endif
     vals[i] = (uint32_t)i;
+}
+
+// cell start tables of the linear octree: entry c of level l = first sorted photon whose key prefix is >= c
+__global__ __launch_bounds__(256) void k_cell_tables(const uint64_t *keys, long long n, uint32_t *cells, int lmax) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= cell_off(lmax + 1)) return;
+    int l = 0;
+    while (l < lmax && t >= cell_off(l + 1)) l++;
+    unsigned long long c = (unsigned long long)(t - cell_off(l));
+    long long lo = 0, hi = n;
+    if (c >> (3 * l)) lo = n;   // the sentinel entry 8^l
+    else {
+        unsigned long long target = l == 0 ? 0ULL : c << (63 - 3 * l);
+        while (lo < hi) { long long mid = (lo + hi) >> 1; if (keys[mid] < target) lo = mid + 1; else hi = mid; }
+    }
+    cells[t] = (uint32_t)lo;
 }
 
 // sorted order -> the two 16-byte streams the gather reads

@@ -12,6 +12,7 @@
 #pragma once
 #include "pm_device.h"
 #include "pm_knn.h"
+#include "pm_grid.h"
 
 namespace pm {
 
@@ -322,7 +323,11 @@ __global__ __launch_bounds__(256) void k_knn_query(MapView m, const double *pts,
 #ifdef PM_STAMPS
         unsigned long long tq0 = __builtin_amdgcn_s_memtime();
 #endif
+#if PM_USE_GRID
+        int f = grid_query(st, buf, m, p, r);
+#else
         int f = knn_query(st, buf, m, p, r);
+#endif
 #ifdef PM_STAMPS
         // diagnostic build: the four work words carry cycles (total, node sections, leaf sections, reduces) instead
         unsigned long long tq1 = __builtin_amdgcn_s_memtime();

@@ -47,7 +47,14 @@ struct MapView {
     int top;                     // index of the top level (its nodes are the root's children)
     const BoxRec *lv[MAX_LEVELS];// lv[0] = leaf boxes (64 photons each), lv[t] = boxes of 64 lv[t-1] nodes
     int cnt[MAX_LEVELS];
+    // linear octree (pm_grid.h): per-level cell start tables over the key-sorted photons
+    const uint64_t *keys;        // sorted 63-bit Morton keys (levels below lmax are resolved by binary search)
+    const uint32_t *cells;       // level l occupies [cell_off(l), cell_off(l) + 8^l] (8^l + 1 entries)
+    int lmax;                    // finest level
+    float glo[3], gext;          // cubic quantisation grid: fine index = (p - glo) / gext * 2^21
+    double gu;                   // size of a fine unit: gext / 2^21
 };
+__host__ __device__ inline long long cell_off(int l) { return (((1LL << (3 * l)) - 1) / 7) + l; }
 
 // per-wave LDS working set
 struct KnnBuf {
@@ -55,6 +62,7 @@ struct KnnBuf {
     uint32_t i[KBUF];            // photon index in sorted order
     unsigned long long acc[4];   // fixed-point radiance accumulators (3 used)
     uint32_t hist[64];           // d2 histogram of the select
+    uint32_t cellpre[128];       // scan list of the grid query (pm_grid.h)
 };
 
 // ---- wave-wide reductions on the DPP network (no LDS round trips); result is wave-uniform
@@ -64,6 +72,7 @@ struct KnnBuf {
 __device__ inline float fmin_op(float a, float b) { return fminf(a, b); }
 __device__ inline uint32_t or_op(uint32_t a, uint32_t b) { return a | b; }
 __device__ inline uint32_t and_op(uint32_t a, uint32_t b) { return a & b; }
+__device__ inline uint32_t umax_op(uint32_t a, uint32_t b) { return a > b ? a : b; }
 #define PM_WAVE_REDUCE(NAME, T, OP)                                                     \
     __device__ inline T NAME(T v) {                                                     \
         PM_DPP_STEP(T, OP, 0xb1, 0xf)  /* quad_perm [1,0,3,2] */                       \
@@ -405,6 +414,16 @@ __device__ inline void photon_term(const float4 &pp, const uint4 &rr, const V3 &
     }
 }
 
+#ifndef PM_USE_GRID
+#define PM_USE_GRID 1
+#endif
+__device__ inline int grid_query(KnnState &st, KnnBuf *buf, const MapView &m, const V3 &q, double &r);   // pm_grid.h
+#if PM_USE_GRID
+#define KNN_QUERY grid_query
+#else
+#define KNN_QUERY knn_query
+#endif
+
 constexpr double FX_SCALE = 72057594037927936.0;   // 2^56
 
 // query + radiance estimate; result valid in every lane
@@ -412,7 +431,7 @@ template <int KIND>
 __device__ inline void knn_gather(KnnBuf *buf, const MapView &m, const V3 &p, const V3 &nrm, double &R, double &G, double &B) {
     KnnState st;
     double r;
-    int found = knn_query(st, buf, m, p, r);
+    int found = KNN_QUERY(st, buf, m, p, r);
     R = G = B = 0.0;
     if (found == 0) return;
     if (st.lane < 3) buf->acc[st.lane] = 0ULL;

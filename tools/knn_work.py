@@ -8,7 +8,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 ctx = ra.Context(0); ctx.upload_scene(ra.default_scene())
 rp = ctx.params(1440, 1440, 12345)
 ids, pts, nrm = ctx.primary_hits(rp)
-sel = np.flatnonzero(ids.ravel() >= 0)[::8]
+only = sys.argv[2] if len(sys.argv) > 2 else 'walls'
+flat = ids.ravel()
+sel = np.flatnonzero((flat >= 0) & (flat <= 4))[::8] if only == 'walls' else np.flatnonzero(flat >= 5)[::2]
 for kind in (0, 1):
     m = ctx.create_map(kind, n, 12345)
     t = time.time(); found, idx, d2, work = ctx.knn_profile(m, pts[sel]); dt = time.time() - t
