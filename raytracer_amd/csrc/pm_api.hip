@@ -60,7 +60,7 @@ struct pm_ctx {
     DevBuf scene;
     SceneView gv{};
     // frame work buffers (grow only, reused across frames)
-    DevBuf geo, obj, pixel, node, tabslot, direct, radg, radc, color, clist, tab, ctr, pane;
+    DevBuf geo, obj, pixel, node, tabslot, direct, radg, radc, color, clist, tab, ctr, pane, sched;
     uint32_t sp_cap = 0;
     Counters *h_ctr = nullptr;   // pinned
     uint64_t *h_u64 = nullptr;   // pinned scratch (2 words)
@@ -73,7 +73,7 @@ struct pm_ctx {
 struct pm_map {
     pm_ctx *ctx = nullptr;
     long long n = 0;
-    DevBuf records, pos4, rest, boxes, cells, keys;
+    DevBuf records, pos4, rest, boxes, cells, keys, cbox;
     MapView view{};
 };
 
@@ -106,7 +106,7 @@ extern "C" int pm_ctx_destroy(pm_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->scene, &ctx->geo, &ctx->obj, &ctx->pixel, &ctx->node, &ctx->tabslot, &ctx->direct, &ctx->radg, &ctx->radc,
-                      &ctx->color, &ctx->clist, &ctx->tab, &ctx->ctr, &ctx->pane, &ctx->emit_tmp, &ctx->emit_flag, &ctx->emit_counts,
+                      &ctx->color, &ctx->clist, &ctx->tab, &ctx->ctr, &ctx->pane, &ctx->sched, &ctx->emit_tmp, &ctx->emit_flag, &ctx->emit_counts,
                       &ctx->emit_offs, &ctx->emit_out, &ctx->keys_in, &ctx->keys_out, &ctx->vals_in, &ctx->vals_out, &ctx->sort_tmp, &ctx->bounds};
     for (DevBuf *b : bufs) b->release();
     if (ctx->h_ctr) (void)hipHostFree(ctx->h_ctr);
@@ -240,13 +240,19 @@ static int build_index(pm_map *map) {
     HIPCHK(hipMemcpyAsync(map->keys.p, ctx->keys_out.p, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(k_cell_tables, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, ctx->stream, ctx->keys_out.as<uint64_t>(), n,
                        map->cells.as<uint32_t>(), lmax);
+    PMCHK(map->cbox.ensure((size_t)box_off(lmax + 1) * 8));
+    hipLaunchKernelGGL(k_cell_boxes_fine, dim3((unsigned)(((1LL << (3 * lmax)) * 64 + 255) / 256)), dim3(256), 0, ctx->stream, map->pos4.as<float4>(),
+                       map->cells.as<uint32_t>(), lmax, ctx->bounds.as<uint32_t>(), map->cbox.as<uint64_t>());
+    for (int l = lmax - 1; l >= 0; l--)
+        hipLaunchKernelGGL(k_cell_boxes_up, dim3((unsigned)(((1LL << (3 * l)) + 255) / 256)), dim3(256), 0, ctx->stream, map->cells.as<uint32_t>(), l,
+                           map->cbox.as<uint64_t>());
     uint32_t hb[6];
     HIPCHK(hipMemcpyAsync(hb, ctx->bounds.p, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     auto ord2f_host = [](uint32_t u) { uint32_t b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; memcpy(&f, &b, 4); return f; };
     float gext = 0.f;
     for (int a = 0; a < 3; a++) { v.glo[a] = ord2f_host(hb[a]); gext = std::max(gext, ord2f_host(hb[3 + a]) - v.glo[a]); }
-    v.gext = gext; v.gu = (double)gext / 2097152.0; v.lmax = lmax; v.cells = map->cells.as<uint32_t>(); v.keys = map->keys.as<uint64_t>();
+    v.gext = gext; v.gu = (double)gext / 2097152.0; v.lmax = lmax; v.cells = map->cells.as<uint32_t>(); v.keys = map->keys.as<uint64_t>(); v.cbox = map->cbox.as<uint64_t>();
     // level sizes
     int cnt[MAX_LEVELS];
     int top = 0;
@@ -337,7 +343,7 @@ extern "C" int pm_map_download(pm_map *map, pm_photon *host_out) {
 extern "C" int pm_map_destroy(pm_map *map) {
     if (!map) return PM_OK;
     if (map->ctx) { (void)hipSetDevice(map->ctx->device); (void)hipStreamSynchronize(map->ctx->stream); }
-    map->records.release(); map->pos4.release(); map->rest.release(); map->boxes.release(); map->cells.release(); map->keys.release();
+    map->records.release(); map->pos4.release(); map->rest.release(); map->boxes.release(); map->cells.release(); map->keys.release(); map->cbox.release();
     delete map;
     return PM_OK;
 }
@@ -543,9 +549,11 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
         HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
         unsigned blocks; uint32_t waves;
         gather_grid(n_sp, blocks, waves);
-        if (!(rp->flags & PM_FLAG_NO_GLOBAL)) { hipLaunchKernelGGL(k_gather<0>, dim3(blocks), block, 0, ctx->stream, gmap->view, q, n_sp); n_gathers++; }
+        PMCHK(ctx->sched.ensure(2 * SCHED_WORDS * 4 + 2 * 8192 * 16));
+        HIPCHK(hipMemsetAsync(ctx->sched.p, 0, 2 * SCHED_WORDS * 4, ctx->stream));   // 64 work counters per gather launch
+        if (!(rp->flags & PM_FLAG_NO_GLOBAL)) { hipLaunchKernelGGL(k_gather<0>, dim3(blocks), block, 0, ctx->stream, gmap->view, q, n_sp, ctx->sched.as<uint32_t>()); n_gathers++; }
         HIPCHK(hipEventRecord(ctx->ev[4], ctx->stream));
-        if (!(rp->flags & PM_FLAG_NO_CAUSTIC)) { hipLaunchKernelGGL(k_gather<1>, dim3(blocks), block, 0, ctx->stream, cmap->view, q, n_sp); n_gathers++; }
+        if (!(rp->flags & PM_FLAG_NO_CAUSTIC)) { hipLaunchKernelGGL(k_gather<1>, dim3(blocks), block, 0, ctx->stream, cmap->view, q, n_sp, ctx->sched.as<uint32_t>() + SCHED_WORDS); n_gathers++; }
         HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));
         LAUNCH_SCENE(k_shade, dim3((n_sp + 255) / 256), block, ctx, fp, q, n_sp, d_pane, tab);
     } else {
@@ -561,6 +569,13 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
         }
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
+#ifdef PM_WAVE_TIMES
+    if (const char *path = getenv("PM_WAVE_DUMP")) {
+        std::vector<uint32_t> h(2 * 8192 * 4);
+        if (n_sp && hipMemcpy(h.data(), ctx->sched.as<uint32_t>() + 2 * SCHED_WORDS, h.size() * 4, hipMemcpyDeviceToHost) == hipSuccess)
+            if (FILE *f = fopen(path, "wb")) { fwrite(h.data(), 4, h.size(), f); fclose(f); }
+    }
+#endif
     if (stats) {
         size_t px = 0;
         for (int b = rp->rank; b < nblk; b += rp->world) px += (std::min<size_t>((size_t)(b + 1) * PM_ROW_BLOCK, (size_t)H) - (size_t)b * PM_ROW_BLOCK) * W;

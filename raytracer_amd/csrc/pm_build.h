@@ -198,6 +198,59 @@ __global__ __launch_bounds__(256) void k_cell_tables(const uint64_t *keys, long 
     cells[t] = (uint32_t)lo;
 }
 
+// ---- tight boxes of the octree cells (pm_grid.h): per cell and axis the lowest and highest occupied 1/1024 slice,
+// 6 x 10 bits in one 64-bit word.  Photon sets are flat (they lie on surfaces) while cells are cubes: the box of a
+// floor cell is a slab, and a query ball that dips into the cube without reaching the floor can drop the cell.
+__device__ inline uint64_t pack_box(const uint32_t lo[3], const uint32_t hi[3]) {
+    uint64_t w = 0;
+    for (int a = 0; a < 3; a++) w |= ((uint64_t)lo[a] << (20 * a)) | ((uint64_t)hi[a] << (20 * a + 10));
+    return w;
+}
+// finest table level: one wave per cell, lanes stride over its photons (a caustic focus puts 10^5 photons in one cell)
+__global__ __launch_bounds__(256) void k_cell_boxes_fine(const float4 *pos4, const uint32_t *cells, int lmax, const uint32_t *bounds, uint64_t *cbox) {
+    long long c = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    int lane = threadIdx.x & 63;
+    if (c >= (1LL << (3 * lmax))) return;
+    const uint32_t *tab = cells + cell_off(lmax);
+    uint32_t first = tab[c], end = tab[c + 1];
+    if (first == end) return;
+    float glo[3] = {ord2f(bounds[0]), ord2f(bounds[1]), ord2f(bounds[2])}, ext = 0.f;
+    for (int a = 0; a < 3; a++) ext = fmaxf(ext, ord2f(bounds[3 + a]) - glo[a]);
+    const int sh = 21 - lmax;   // >= 13
+    uint32_t lo[3] = {1023u, 1023u, 1023u}, hi[3] = {0u, 0u, 0u};
+    for (uint32_t i = first + (uint32_t)lane; i < end; i += 64u) {
+        float4 p = pos4[i];
+        float pa[3] = {p.x, p.y, p.z};
+        for (int a = 0; a < 3; a++) {
+            uint32_t sub = (quant21(pa[a], glo[a], ext) & ((1u << sh) - 1u)) >> (sh - 10);
+            lo[a] = min(lo[a], sub); hi[a] = max(hi[a], sub);
+        }
+    }
+    for (int a = 0; a < 3; a++)
+        for (int s = 1; s < 64; s <<= 1) { lo[a] = min(lo[a], (uint32_t)__shfl_xor((int)lo[a], s)); hi[a] = max(hi[a], (uint32_t)__shfl_xor((int)hi[a], s)); }
+    if (lane == 0) cbox[box_off(lmax) + c] = pack_box(lo, hi);
+}
+// level l from level l + 1: union of the non-empty children, halved into the parent's 1/1024 slices
+__global__ __launch_bounds__(256) void k_cell_boxes_up(const uint32_t *cells, int l, uint64_t *cbox) {
+    long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (1LL << (3 * l))) return;
+    const uint32_t *tab = cells + cell_off(l + 1);
+    uint32_t lo[3] = {1023u, 1023u, 1023u}, hi[3] = {0u, 0u, 0u};
+    bool any = false;
+    for (int j = 0; j < 8; j++) {
+        long long k = 8 * c + j;
+        if (tab[k] == tab[k + 1]) continue;
+        any = true;
+        uint64_t w = cbox[box_off(l + 1) + k];
+        for (int a = 0; a < 3; a++) {
+            uint32_t half = ((uint32_t)(j >> a) & 1u) * 512u;
+            lo[a] = min(lo[a], half + (((uint32_t)(w >> (20 * a)) & 1023u) >> 1));
+            hi[a] = max(hi[a], half + (((uint32_t)(w >> (20 * a + 10)) & 1023u) >> 1));
+        }
+    }
+    if (any) cbox[box_off(l) + c] = pack_box(lo, hi);
+}
+
 // sorted order -> the two 16-byte streams the gather reads
 __global__ __launch_bounds__(256) void k_permute(const pm_photon *ph, const uint32_t *order, long long n, float4 *pos4, uint4 *rest) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -2,24 +2,20 @@
 // key, so every aligned cell of every level is ONE contiguous range of the sorted array, looked up in
 // per-level start tables.  Replaces find_nearest_photons + insert (reference src/PhotonMap.cpp:142-255).
 //
-// A query picks the finest level whose cells still hold enough photons around it, takes the 3x3x3
-// block of cells around its own cell (27 lanes: one cell each), and scans the photons of those cells
-// 64 at a time (coalesced 16-byte loads).  Everything closer than g, the distance from the query to the
-// nearest face of the block, is guaranteed to be in the block, so the 63 nearest found are exact as soon
-// as the 63rd distance is below g; otherwise the query is repeated one level coarser.  Candidates go to
-// the per-wave LDS buffer and the histogram + radix select of pm_knn.h picks the exact 63rd distance.
+// A query is a best-first walk over octree cells with the 64 lanes of the wave as the queue (one cell per
+// lane).  The queue starts as an exact cover of space: the query's own cell at the finest table level and
+// the 7 siblings of its ancestor at every level above (one table lookup per lane).  Each round either
+// scans, 64 photons at a time (coalesced 16-byte loads), the small cells that are nearer than every cell
+// still too big to scan, or splits the nearest big cells into their 8 children.  Cells whose distance
+// from the query is not below the running bound `lim` are dropped; `lim` falls to the exact 63rd-smallest
+// distance each time the candidate buffer is reduced (histogram + radix select of pm_knn.h).  The walk
+// ends when no cell is left, so the result is exact wherever the query lies -- on a photon-bearing
+// surface (a handful of cells), or far from every photon (only the cells its ball reaches).
 #pragma once
 #include "pm_knn.h"
 #include "pm_hilbert.h"
 
 namespace pm {
-
-#ifndef PM_GRID_T_OWN
-#define PM_GRID_T_OWN 12       // finest level whose own cell holds at least this many photons
-#endif
-#ifndef PM_GRID_EST
-#define PM_GRID_EST 80         // expected photons inside the guaranteed ball needed to try a level
-#endif
 
 __device__ inline uint32_t quant21(float p, float lo, float ext) {   // shared by build and query
     float t = ext > 0.f ? (p - lo) / ext : 0.f;
@@ -27,17 +23,18 @@ __device__ inline uint32_t quant21(float p, float lo, float ext) {   // shared b
 }
 __device__ inline uint64_t morton63(uint32_t x, uint32_t y, uint32_t z) { return spread21(x) | (spread21(y) << 1) | (spread21(z) << 2); }
 
-__device__ inline uint32_t wave_sum_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl_u32(v), 63); }
-
-// Scan the photons of the 3x3x3 block at `level`; returns true when the result in the buffer is exact.
 #ifndef PM_GRID_SPLIT
-#define PM_GRID_SPLIT 192      // a cell of the scan list holding more photons than this is split into its 8 children
+#define PM_GRID_SPLIT 128      // a queued cell holding more photons than this is split into its 8 children before it is read
+#endif
+#ifndef PM_GRID_SLACK
+#define PM_GRID_SLACK 24       // candidates beyond 63 that make a reduce worth its cost (a tighter lim prunes cells)
+#endif
+#ifndef PM_GRID_MULTI
+#define PM_GRID_MULTI 4        // big cells split per round once lim is an actual k-th distance
 #endif
 
-PM_WAVE_REDUCE(wave_max_u32, uint32_t, umax_op)
-
 // photon range [first, first + cnt) of the cell with Morton key `key` at `level`; below the finest table the
-// cell is a sub-range of [plo, pend) (its parent's or ancestor's range): two binary searches on the sorted keys
+// cell is a sub-range of [plo, pend) (its parent's range): two binary searches on the sorted keys
 __device__ inline void cell_range(const MapView &m, int level, uint64_t key, uint32_t plo, uint32_t pend, uint32_t &first, uint32_t &cnt) {
     if (level <= m.lmax) {
         const uint32_t *tab = m.cells + cell_off(level);
@@ -53,154 +50,115 @@ __device__ inline void cell_range(const MapView &m, int level, uint64_t key, uin
     while (a < b) { uint32_t mid = (a + b) >> 1; if ((m.keys[mid] >> ks) <= key) a = mid + 1; else b = mid; }
     cnt = a - first;
 }
-// squared distance from q to the cell (cx,cy,cz) of `level`, shrunk by the two-fine-unit binning margin
-__device__ inline double cell_d2(const MapView &m, const V3 &q, int level, uint32_t cx, uint32_t cy, uint32_t cz) {
-    double h = (double)(1u << (21 - level)) * m.gu, d2 = 0.0;
+// key of a cell: 3 * level bits.  Table levels fit 32-bit arithmetic.
+__device__ inline uint32_t spread10(uint32_t v) {   // 10 bits -> every third bit
+    v &= 0x3FFu;
+    v = (v | v << 16) & 0x030000FFu;
+    v = (v | v << 8) & 0x0300F00Fu;
+    v = (v | v << 4) & 0x030C30C3u;
+    v = (v | v << 2) & 0x09249249u;
+    return v;
+}
+__device__ inline uint64_t cell_key(int level, uint32_t cx, uint32_t cy, uint32_t cz) {
+    if (level <= 10) return (uint64_t)(spread10(cx) | spread10(cy) << 1 | spread10(cz) << 2);
+    return morton63(cx, cy, cz);
+}
+
+// squared distances from q to the nearest and the farthest point of the box of cell (cx,cy,cz) of `level`: the occupied
+// slices of the cell where the map stores them (table levels), the whole cube below; either way grown by the
+// two-fine-unit binning margin (photons were binned with float arithmetic).  dmin2 is never above, dmax2 never below
+// the d2 of a photon filed in the cell.
+__device__ inline void cell_d2(const MapView &m, const V3 &q, int level, uint32_t cx, uint32_t cy, uint32_t cz, uint64_t key, bool boxed,
+                               double &dmin2, double &dmax2) {
+    const int sh = 21 - level;
+    uint32_t lo_s[3] = {0u, 0u, 0u}, hi_s[3] = {1u << sh, 1u << sh, 1u << sh};   // in fine units from the cell's corner
+    if (boxed) {   // level <= lmax <= 8: a slice is 2^(sh-10) >= 8 fine units
+        uint64_t w = m.cbox[box_off(level) + (long long)key];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            lo_s[a] = ((uint32_t)(w >> (20 * a)) & 1023u) << (sh - 10);
+            hi_s[a] = (((uint32_t)(w >> (20 * a + 10)) & 1023u) + 1u) << (sh - 10);
+        }
+    }
+    dmin2 = dmax2 = 0.0;
     const uint32_t cc[3] = {cx, cy, cz};
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         double qa = a == 0 ? q.x : (a == 1 ? q.y : q.z);
-        double lo_face = (double)m.glo[a] + (double)cc[a] * h - 2.0 * m.gu, hi_face = lo_face + h + 4.0 * m.gu;
+        uint32_t o = cc[a] << sh;
+        double lo_face = (double)m.glo[a] + ((double)(o + lo_s[a]) - 2.0) * m.gu, hi_face = (double)m.glo[a] + ((double)(o + hi_s[a]) + 2.0) * m.gu;
         double gap = qa < lo_face ? lo_face - qa : (qa > hi_face ? qa - hi_face : 0.0);
-        d2 += gap * gap;
+        double far = fmax(fabs(qa - lo_face), fabs(hi_face - qa));
+        dmin2 += gap * gap;
+        dmax2 += far * far;
     }
-    return d2;
 }
 
-// verdict: 0 = scanned (return value says whether the result is exact), -1 = too sparse, go coarser, +1 = far denser than
-// needed, go finer (only offered while allow_finer)
-__device__ inline bool grid_attempt(KnnState &st, const MapView &m, const V3 &q, const uint32_t qf[3], int level, bool allow_finer, int &verdict) {
+// Offer every photon of the cells flagged `take` (ranges [first, first + cnt) per lane): the ranges are laid end to
+// end and read 64 photons at a time; candidates closer than lim go to the buffer.
+__device__ inline void grid_scan(KnnState &st, const MapView &m, const V3 &q, bool take, uint32_t first, uint32_t cnt) {
     const int lane = st.lane;
-    const int sh = 21 - level;
-    const uint32_t ncell = 1u << level;
-    // this lane's cell of the block (lanes 0..26); every lane later holds one cell of the scan list
-    int dx = lane % 3 - 1, dy = (lane / 3) % 3 - 1, dz = lane / 9 - 1;
-    long long bx = (long long)(qf[0] >> sh) + dx, by = (long long)(qf[1] >> sh) + dy, bz = (long long)(qf[2] >> sh) + dz;
-    bool cell_ok = lane < 27 && bx >= 0 && by >= 0 && bz >= 0 && bx < ncell && by < ncell && bz < ncell;
-    int clev = level;
-    uint32_t cx = cell_ok ? (uint32_t)bx : 0u, cy = cell_ok ? (uint32_t)by : 0u, cz = cell_ok ? (uint32_t)bz : 0u;
-    uint32_t first = 0, cnt = 0;
-    if (cell_ok) {
-        uint64_t key = morton63(cx, cy, cz);   // 3*level bits
-        uint32_t plo = 0, pend = 0;
-        if (level > m.lmax) {
-            const uint32_t *tab = m.cells + cell_off(m.lmax);
-            uint64_t anc = key >> (3 * (level - m.lmax));
-            plo = tab[anc]; pend = tab[anc + 1];
-        }
-        cell_range(m, level, key, plo, pend, first, cnt);
-    }
-    uint32_t total = wave_sum_u32(cnt);
-    // g: everything closer than this to q is inside the block (photons were binned with float arithmetic:
-    // two fine units of margin).  A side on which the block reaches the border of the grid does not limit g.
-    double g2 = MAX_R2;
-    bool covers = true;
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        long long c = (long long)(qf[a] >> sh);
-        double qa = a == 0 ? q.x : (a == 1 ? q.y : q.z);
-        if (c - 1 > 0) {
-            double face = (double)m.glo[a] + ((double)((c - 1) << sh) + 2.0) * m.gu;
-            double g = qa - face;
-            covers = false;
-            g2 = fmin(g2, g > 0 ? g * g : 0.0);
-        }
-        if (c + 2 < (long long)ncell) {
-            double face = (double)m.glo[a] + ((double)((c + 2) << sh) - 2.0) * m.gu;
-            double g = face - qa;
-            covers = false;
-            g2 = fmin(g2, g > 0 ? g * g : 0.0);
-        }
-    }
-    if (!covers) {
-        // cheap rejection before any photon is read: expected photons inside the guaranteed ball, taking the
-        // photons of the block to lie on a surface through it (area 9 h^2)
-        double h = (double)(1u << sh) * m.gu;
-        double est = (double)total * (3.14159 * g2) / (9.0 * h * h);
-        if (est < (double)PM_GRID_EST) { verdict = -1; return false; }
-        if (allow_finer && level < 21 && est >= 4.0 * (double)PM_GRID_EST) { verdict = 1; return false; }
-    }
-    verdict = 0;
-    // Only d2 < lim is useful for THIS attempt: beyond g the block is not complete.
-    st.lim = covers ? MAX_R2 : fmin(MAX_R2, g2);
-    st.count = 0;
-    st.reduced = false;
-    if (cnt > 0 && cell_d2(m, q, clev, cx, cy, cz) >= st.lim) cnt = 0;   // cell entirely beyond lim
-    // Refine the scan list: while some cell is much fuller than a query needs (a caustic focus next to a sparse
-    // spot, a dense floor below an off-surface query), replace it by those of its 8 children that still reach
-    // into the lim ball.  Children are contiguous sub-ranges of the parent (Morton order).
-    for (int round = 0; round < 16; round++) {
-        uint32_t mx = wave_max_u32(cnt);
-        if (mx <= (uint32_t)PM_GRID_SPLIT) break;
-        unsigned long long freem = __ballot(cnt == 0 || cnt == mx);
-        int big = __ffsll((long long)__ballot(cnt == mx)) - 1;
-        freem |= 1ULL << big;
-        // only ONE cell with cnt == mx is split; other cells with the same count keep their lane
-        unsigned long long same = __ballot(cnt == mx) & ~(1ULL << big);
-        freem &= ~same;
-        if (__popcll(freem) < 8) break;
-        int plev = __builtin_amdgcn_readlane(clev, big);
-        if (plev >= 21) break;
-        uint32_t px = (uint32_t)__builtin_amdgcn_readlane((int)cx, big), py = (uint32_t)__builtin_amdgcn_readlane((int)cy, big),
-                 pz = (uint32_t)__builtin_amdgcn_readlane((int)cz, big);
-        uint32_t pfirst = (uint32_t)__builtin_amdgcn_readlane((int)first, big), pcnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt, big);
-        int j = lane_rank(freem);
-        bool is_child = ((freem >> lane) & 1ULL) && j < 8;
-        if (lane == big) cnt = 0;
-        if (is_child) {
-            clev = plev + 1;
-            cx = 2 * px + (uint32_t)(j & 1); cy = 2 * py + (uint32_t)((j >> 1) & 1); cz = 2 * pz + (uint32_t)(j >> 2);
-            cell_range(m, clev, morton63(cx, cy, cz), pfirst, pfirst + pcnt, first, cnt);
-            if (cnt > 0 && cell_d2(m, q, clev, cx, cy, cz) >= st.lim) cnt = 0;
-        }
-    }
-    uint32_t incl = wave_scan_incl_u32(cnt);
-    total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    uint32_t *pre = st.buf->cellpre;         // [0..63] inclusive prefix of the non-empty cells, [64..127] index offset of each
-    unsigned long long nonempty = __ballot(cnt > 0);
+    uint32_t c = take ? cnt : 0u;
+    uint32_t incl = wave_scan_incl_u32(c);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t *pre = st.buf->cellpre;         // [0..63] inclusive prefix of the taken cells, [64..127] index offset of each
+    unsigned long long nonempty = __ballot(c > 0);
+    const int ncell = __popcll(nonempty);
     int k = lane_rank(nonempty);
     wave_lds_fence();
     pre[lane] = 0xFFFFFFFFu;
     wave_lds_fence();
-    if (cnt > 0) { pre[k] = incl; pre[64 + k] = first - (incl - cnt); }   // second word: add the global position t to get the photon index
+    if (c > 0) { pre[k] = incl; pre[64 + k] = first - (incl - c); }   // second word: add the position t in the list to get the photon index
     wave_lds_fence();
-    for (uint32_t base = 0; base < total; base += 64) {
-        uint32_t t = base + (uint32_t)lane;
-        // number of non-empty cells whose inclusive prefix is <= t  (binary search, 64 slots)
-        int j = 0;
+    // search depth for `ncell` slots: the largest first step s0 with 2 * s0 >= ncell (0 for a single cell)
+    const int s0 = ncell <= 1 ? 0 : 1 << (31 - __clz(ncell - 1));
+    // two chunks of 64 photons per iteration: both index searches and both loads are issued before either is used
+    for (uint32_t base = 0; base < total; base += 128) {
+        uint32_t t[2] = {base + (uint32_t)lane, base + 64u + (uint32_t)lane};
+        uint32_t i[2];
+        bool valid[2];
+        float4 p[2];
 #pragma unroll
-        for (int step = 32; step > 0; step >>= 1)
-            if (pre[j + step - 1] <= t) j += step;
-        bool valid = t < total;
-        uint32_t i = valid ? pre[64 + j] + t : 0u;
-        st.c_leaves++;
-        float4 p = valid ? m.pos4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        double ddx = (double)p.x - q.x, ddy = (double)p.y - q.y, ddz = (double)p.z - q.z;   // src/PhotonMap.cpp:211-214
-        double d2 = ddx * ddx + ddy * ddy + ddz * ddz;
-        bool pass = valid && d2 < st.lim;
-        unsigned long long mask = __ballot(pass);
-        if (mask == 0ULL) continue;
-        if (pass) {
-            int pos = st.count + lane_rank(mask);
-            st.buf->d[pos] = (unsigned long long)__double_as_longlong(d2);
-            st.buf->i[pos] = i;
+        for (int h = 0; h < 2; h++) {
+            // number of taken cells whose inclusive prefix is <= t
+            int j = 0;
+            for (int step = s0; step > 0; step >>= 1)
+                if (pre[j + step - 1] <= t[h]) j += step;
+            valid[h] = t[h] < total;
+            i[h] = valid[h] ? pre[64 + j] + t[h] : 0u;
+            p[h] = valid[h] ? m.pos4[i[h]] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        int np = __popcll(mask);
-        st.count += np;
-        st.c_cands += np;
-        if (st.count >= KBUF - 64) knn_reduce(st);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if (h == 1 && base + 64u >= total) break;
+            st.c_leaves++;
+            double ddx = (double)p[h].x - q.x, ddy = (double)p[h].y - q.y, ddz = (double)p[h].z - q.z;   // src/PhotonMap.cpp:211-214
+            double d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+            bool pass = valid[h] && d2 < st.lim;
+            unsigned long long mask = __ballot(pass);
+            if (mask == 0ULL) continue;
+            if (pass) {
+                int pos = st.count + lane_rank(mask);
+                st.buf->d[pos] = (unsigned long long)__double_as_longlong(d2);
+                st.buf->i[pos] = i[h];
+            }
+            int np = __popcll(mask);
+            st.count += np;
+            st.c_cands += np;
+            if (st.count >= KBUF - 64) knn_reduce(st);
+        }
     }
-    if (st.count > KNN_K) knn_reduce(st);
-    // exact if the block covers everything within reach, or the 63rd distance lies inside the guaranteed ball
-    // (lim was capped at g2, so 63 candidates found means exactly that)
-    return covers || st.count >= KNN_K;
 }
 
 // Full query; same contract as knn_query (pm_knn.h).
-__device__ inline int grid_query(KnnState &st, KnnBuf *buf, const MapView &m, const V3 &q, double &r) {
-    st.lane = threadIdx.x & 63;
+// lim0: a proven bound on the 63rd-smallest d2 (63 photons or more lie closer than it), or MAX_R2 when nothing is
+// known.  Runs of neighbouring queries pass (sqrt(r_prev) + |q - q_prev|)^2: the previous ball lies inside that one.
+__device__ inline int grid_query(KnnState &st, KnnBuf *buf, const MapView &m, const V3 &q, double &r, double lim0) {
+    const float INF = __int_as_float(0x7F800000);
+    const int lane = threadIdx.x & 63;
+    st.lane = lane;
     st.buf = buf;
-    st.lim = MAX_R2;
+    st.lim = fmin(lim0, MAX_R2);
     st.count = 0;
     st.reduced = false;
     st.any_reduce = false;
@@ -210,39 +168,116 @@ __device__ inline int grid_query(KnnState &st, KnnBuf *buf, const MapView &m, co
 #endif
     r = 0.0;
     if (m.n <= 0) return 0;
-    uint32_t qf[3] = {quant21((float)q.x, m.glo[0], m.gext), quant21((float)q.y, m.glo[1], m.gext), quant21((float)q.z, m.glo[2], m.gext)};
-    // level choice: lane l looks up the population of the query's own cell at level l
-    uint64_t qkey = morton63(qf[0], qf[1], qf[2]);
-    uint32_t own = 0;
-    if (st.lane <= m.lmax) {
-        uint64_t key = st.lane == 0 ? 0ULL : (qkey >> (3 * (21 - st.lane)));
-        const uint32_t *tab = m.cells + cell_off(st.lane);
-        own = tab[key + 1] - tab[key];
+    const uint32_t qf[3] = {quant21((float)q.x, m.glo[0], m.gext), quant21((float)q.y, m.glo[1], m.gext), quant21((float)q.z, m.glo[2], m.gext)};
+    // The queue, one cell per lane: lanes 7(l-1) .. 7(l-1)+6 hold the 7 siblings of the query's level-l cell, lane 7*lmax
+    // the query's own cell at level lmax.  Together they tile the whole grid (lmax <= 8: 57 lanes).
+    const int L = m.lmax;
+#ifdef PM_STAMPS
+    unsigned long long ts_ = __builtin_amdgcn_s_memtime();
+#define PM_LAP(field) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); st.field += now_ - ts_; ts_ = now_; }
+#else
+#define PM_LAP(field)
+#endif
+    int lev = 0;
+    uint32_t cx = 0, cy = 0, cz = 0, first = 0, cnt = 0;
+    double dmin2 = 0.0, dmax2 = 0.0;
+    bool fresh_cells = true;
+    bool tight = lim0 < MAX_R2;   // lim is already close to the answer: reduce only when the buffer has grown
+    if (lane <= 7 * L) {
+        int j = 0;
+        if (lane == 7 * L) lev = L;
+        else { lev = lane / 7 + 1; j = lane % 7 + 1; }
+        const int sh = 21 - lev;
+        cx = (lev ? qf[0] >> sh : 0u) ^ (uint32_t)(j & 1);
+        cy = (lev ? qf[1] >> sh : 0u) ^ (uint32_t)((j >> 1) & 1);
+        cz = (lev ? qf[2] >> sh : 0u) ^ (uint32_t)(j >> 2);
+        uint64_t key = cell_key(lev, cx, cy, cz);
+        cell_range(m, lev, key, 0u, 0u, first, cnt);
+        if (cnt > 0) cell_d2(m, q, lev, cx, cy, cz, key, true, dmin2, dmax2);
     }
-    unsigned long long okm = __ballot(own >= (uint32_t)PM_GRID_T_OWN);
-    int level = okm ? 63 - __clzll((long long)okm) : 0;
-    // a query off the photon-bearing surfaces has an empty own cell long before its 3x3x3 block runs dry:
-    // start two levels finer and let the density estimate walk back up (a rejected level costs 27 table reads)
-    if (level < m.lmax) level = min(m.lmax, level + 2);
-    else {
-        // denser than the finest table resolves: photons on a surface thin out 4x per level
-        uint32_t own_f = (uint32_t)__builtin_amdgcn_readlane((int)own, m.lmax) / (uint32_t)PM_GRID_T_OWN;
-        if (own_f >= 4u) level = min(21, m.lmax + (31 - __clz((int)own_f)) / 2);
-    }
-    bool allow_finer = true;
     for (;;) {
-        st.c_nodes++;
-        int verdict = 0;
-        if (grid_attempt(st, m, q, qf, level, allow_finer, verdict)) break;
-        if (verdict > 0) { level++; continue; }
-        allow_finer = false;     // once a level was too sparse (or failed) the walk only goes coarser: no oscillation
-        if (level == 0) break;   // cannot happen: level 0 always covers; belt and braces
-        level--;
+        if (fresh_cells) {
+            // a cell holding 63 photons or more bounds the 63rd distance by its farthest corner, before any photon is read
+            float best = wave_min_f32(cnt >= (uint32_t)KNN_K ? __double2float_ru(dmax2) : INF);
+            if (best < INF) {
+                double bound = __longlong_as_double(__double_as_longlong((double)best) + 1);   // one ulp above: the test is '<'
+                if (bound < st.lim) { st.lim = bound; st.reduced = false; }
+            }
+            fresh_cells = false;
+        }
+        const bool alive = cnt > 0 && dmin2 < st.lim;
+        if (!alive) cnt = 0;
+        const unsigned long long am = __ballot(alive);
+        if (am == 0ULL) break;
+        const bool big = alive && cnt > (uint32_t)PM_GRID_SPLIT && lev < 21;
+        const unsigned long long bm = __ballot(big);
+        const float fkey = (float)dmin2;      // order of the walk only; pruning uses dmin2 itself
+        const float fb = bm ? wave_min_f32(big ? fkey : INF) : INF;
+        // small cells no farther than the nearest big one are read now
+        bool take = alive && !big && fkey <= fb;
+        const int nfree = 64 - __popcll(am);
+        if (__ballot(take) == 0ULL) {
+            if (nfree + 1 >= 8) {
+                // split the nearest big cells: the parent's lane and the idle lanes receive the children
+                st.c_nodes++;
+                int nsplit = st.lim < MAX_R2 ? PM_GRID_MULTI : 1;
+                unsigned long long todo = bm;
+                unsigned long long freem = ~am;
+                bool fresh = false;
+                int plev = 0; uint32_t px = 0, py = 0, pz = 0, pfirst = 0, pcnt = 0; int cj = 0;
+                float fnear = fb;
+                while (nsplit-- > 0 && todo) {
+                    int bl = __ffsll((long long)(__ballot(big && fkey == fnear) & todo)) - 1;
+                    if (bl < 0) break;
+                    unsigned long long fm = freem | (1ULL << bl);
+                    if (__popcll(fm) < 8) break;
+                    int j = lane_rank(fm);
+                    bool mine = ((fm >> lane) & 1ULL) && j < 8;
+                    int l_ = __builtin_amdgcn_readlane(lev, bl);
+                    uint32_t x_ = (uint32_t)__builtin_amdgcn_readlane((int)cx, bl), y_ = (uint32_t)__builtin_amdgcn_readlane((int)cy, bl),
+                             z_ = (uint32_t)__builtin_amdgcn_readlane((int)cz, bl);
+                    uint32_t f_ = (uint32_t)__builtin_amdgcn_readlane((int)first, bl), c_ = (uint32_t)__builtin_amdgcn_readlane((int)cnt, bl);
+                    if (mine) { fresh = true; plev = l_; px = x_; py = y_; pz = z_; pfirst = f_; pcnt = c_; cj = j; }
+                    // the 8 lowest lanes of fm are used up
+                    if (lane == bl && !mine) cnt = 0;   // the parent is replaced by its children
+                    unsigned long long used = __ballot(mine);
+                    freem = fm & ~used;
+                    todo &= ~(1ULL << bl);
+                    if (nsplit > 0 && todo) {
+                        bool rest = big && ((todo >> lane) & 1ULL);
+                        fnear = wave_min_f32(rest ? fkey : INF);
+                    }
+                }
+                if (fresh) {
+                    lev = plev + 1;
+                    cx = 2 * px + (uint32_t)(cj & 1); cy = 2 * py + (uint32_t)((cj >> 1) & 1); cz = 2 * pz + (uint32_t)(cj >> 2);
+                    uint64_t key = cell_key(lev, cx, cy, cz);
+                    cell_range(m, lev, key, pfirst, pfirst + pcnt, first, cnt);
+                    if (cnt > 0) cell_d2(m, q, lev, cx, cy, cz, key, lev <= m.lmax, dmin2, dmax2);
+                }
+                fresh_cells = true;
+                PM_LAP(t_node)
+                continue;
+            }
+            // no room to split: read every small cell to free lanes, or failing that the nearest big cell as it is
+            take = alive && !big;
+            if (__ballot(take) == 0ULL) take = lane == __ffsll((long long)__ballot(big && fkey == fb)) - 1;
+        }
+        PM_LAP(t_node)
+        grid_scan(st, m, q, take, first, cnt);
+        if (take) cnt = 0;
+        PM_LAP(t_leaf)
+        if (st.count >= KNN_K && (!tight || st.count >= KNN_K + PM_GRID_SLACK)) { knn_reduce(st); tight = true; }
+#ifdef PM_STAMPS
+        ts_ = __builtin_amdgcn_s_memtime();
+#endif
     }
+    PM_LAP(t_node)
+    if (st.count > KNN_K) knn_reduce(st);
     if (st.count == 0) return 0;
     wave_lds_fence();
     if (st.reduced) { r = st.lim; return st.count; }
-    double d = st.lane < st.count ? __longlong_as_double((long long)st.buf->d[st.lane]) : 0.0;
+    double d = lane < st.count ? __longlong_as_double((long long)st.buf->d[lane]) : 0.0;
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) d = fmax(d, __shfl_xor(d, s));
     r = d;

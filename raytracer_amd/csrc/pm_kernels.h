@@ -268,26 +268,68 @@ __global__ __launch_bounds__(256) void k_shadow(SceneView gs, FrameParams fp, SP
     q.direct[s] = direct;
 }
 
-// one wave per shade point
+// One draw from a work counter per wave.  Out of line on purpose: inlined into the scheduling loop, the
+// lane-0 branch was threaded into the loop's control flow and lanes 1..63 were sent round the loop on their own.
+__device__ __noinline__ uint32_t wave_draw(uint32_t *ctr) {
+    uint32_t g = 0;
+    if ((threadIdx.x & 63) == 0) g = atomicAdd(ctr, 1u);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+}
+
+#ifndef PM_GATHER_GROUP
+#define PM_GATHER_GROUP 4      // consecutive shade points (neighbouring pixels) per draw
+#endif
+constexpr uint32_t SCHED_CHUNK = 1024;   // shade points per chunk; chunk c belongs to counter c % 64
+constexpr uint32_t SCHED_STRIDE = 32;    // one counter per 128-byte line
+constexpr uint32_t SCHED_WORDS = 64 * SCHED_STRIDE;
+static_assert(SCHED_CHUNK % PM_GATHER_GROUP == 0, "a draw must not straddle two chunks");
+// One wave per shade point, work drawn from device counters.  The queue is cut into chunks of 1024 consecutive shade
+// points (a strip of the image, so a compact part of the photon map); chunk c is served by counter c % 64 and counter k
+// by the blocks of XCD k % 8 (blocks b, b+8, ... share an XCD and its L2).  A wave starts on one of its XCD's 8 counters
+// and moves to the next when that runs dry, so a cluster of expensive queries never becomes one wave's tail and no
+// counter sees more than a few thousand draws.
 template <int KIND>
-__global__ __launch_bounds__(256) void k_gather(MapView m, SPQueue q, uint32_t n_sp) {
+__global__ __launch_bounds__(256) void k_gather(MapView m, SPQueue q, uint32_t n_sp, uint32_t *sched) {
     __shared__ KnnBuf bufs[4];
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler should know
     KnnBuf *buf = &bufs[wave_in_block];
     int lane = threadIdx.x & 63;
     double *out = KIND == 0 ? q.rad_g : q.rad_c;
-    // blocks b, b+8, b+16, ... share an XCD (and its L2): give each XCD one contiguous eighth of the
-    // queue (= a band of the image, so a compact part of the photon map) and stride its waves over it
-    uint32_t xcd = blockIdx.x & 7, nx = gridDim.x >> 3;
-    uint32_t lo = (uint32_t)(((uint64_t)n_sp * xcd) >> 3), hi = (uint32_t)(((uint64_t)n_sp * (xcd + 1)) >> 3);
-    uint32_t wl = (blockIdx.x >> 3) * 4 + (uint32_t)wave_in_block, wpx = nx * 4;
-    for (uint32_t s = lo + wl; s < hi; s += wpx) {
-        V3 p = {q.geo[0 * (size_t)q.cap + s], q.geo[1 * (size_t)q.cap + s], q.geo[2 * (size_t)q.cap + s]};
-        V3 nrm = {q.geo[3 * (size_t)q.cap + s], q.geo[4 * (size_t)q.cap + s], q.geo[5 * (size_t)q.cap + s]};
-        double R, G, B;
-        knn_gather<KIND>(buf, m, p, nrm, R, G, B);
-        if (lane == 0) { out[0 * (size_t)q.cap + s] = R; out[1 * (size_t)q.cap + s] = G; out[2 * (size_t)q.cap + s] = B; }
+    const uint32_t xcd = blockIdx.x & 7;
+    uint32_t sub = (blockIdx.x >> 3) & 7;
+#ifdef PM_WAVE_TIMES
+    unsigned long long wt0 = __builtin_amdgcn_s_memtime(); uint32_t wq = 0;
+#endif
+    for (uint32_t tries = 0; tries < 8;) {
+        const uint32_t c = xcd + 8 * sub;
+        uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_draw(&sched[c * SCHED_STRIDE]));
+        uint32_t li = g * (uint32_t)PM_GATHER_GROUP;
+        uint64_t s0 = ((uint64_t)c + 64ull * (li / SCHED_CHUNK)) * SCHED_CHUNK + li % SCHED_CHUNK;
+        if (s0 >= n_sp) { tries++; sub = (sub + 1) & 7; continue; }   // this counter is exhausted (s0 grows with every draw)
+        uint32_t s1 = (uint32_t)s0 + (uint32_t)PM_GATHER_GROUP;
+        if (s1 > n_sp) s1 = n_sp;
+        KnnCarry carry;
+        carry.full = false;
+        for (uint32_t s = (uint32_t)s0; s < s1; s++) {
+            V3 p = {q.geo[0 * (size_t)q.cap + s], q.geo[1 * (size_t)q.cap + s], q.geo[2 * (size_t)q.cap + s]};
+            V3 nrm = {q.geo[3 * (size_t)q.cap + s], q.geo[4 * (size_t)q.cap + s], q.geo[5 * (size_t)q.cap + s]};
+            double R, G, B;
+            knn_gather<KIND>(buf, m, p, nrm, R, G, B, carry);
+            if (lane == 0) { out[0 * (size_t)q.cap + s] = R; out[1 * (size_t)q.cap + s] = G; out[2 * (size_t)q.cap + s] = B; }
+#ifdef PM_WAVE_TIMES
+            wq++;
+#endif
+        }
     }
+#ifdef PM_WAVE_TIMES
+    // diagnostic build: per wave {start, end, queries} after the counters
+    if (lane == 0) {
+        uint32_t w = blockIdx.x * 4 + wave_in_block;
+        unsigned long long wt1 = __builtin_amdgcn_s_memtime();
+        uint32_t *o = sched + 2 * SCHED_WORDS + (size_t)KIND * 8192 * 4 + (size_t)w * 4;
+        o[0] = (uint32_t)wt0; o[1] = (uint32_t)wt1; o[2] = wq; o[3] = xcd;
+    }
+#endif
 }
 
 // standalone gather on caller-provided points (pm_knn_gather): points/normals/radiance are [m][3]
@@ -304,7 +346,9 @@ __global__ __launch_bounds__(256) void k_gather_points(MapView m, const double *
         V3 p = {pts[3 * s], pts[3 * s + 1], pts[3 * s + 2]};
         V3 nrm = {nrms[3 * s], nrms[3 * s + 1], nrms[3 * s + 2]};
         double R, G, B;
-        knn_gather<KIND>(buf, m, p, nrm, R, G, B);
+        KnnCarry carry;
+        carry.full = false;
+        knn_gather<KIND>(buf, m, p, nrm, R, G, B, carry);
         if (lane == 0) { rad[3 * s] = R; rad[3 * s + 1] = G; rad[3 * s + 2] = B; }
     }
 }
@@ -324,7 +368,7 @@ __global__ __launch_bounds__(256) void k_knn_query(MapView m, const double *pts,
         unsigned long long tq0 = __builtin_amdgcn_s_memtime();
 #endif
 #if PM_USE_GRID
-        int f = grid_query(st, buf, m, p, r);
+        int f = grid_query(st, buf, m, p, r, MAX_R2);
 #else
         int f = knn_query(st, buf, m, p, r);
 #endif

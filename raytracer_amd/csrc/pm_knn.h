@@ -50,11 +50,13 @@ struct MapView {
     // linear octree (pm_grid.h): per-level cell start tables over the key-sorted photons
     const uint64_t *keys;        // sorted 63-bit Morton keys (levels below lmax are resolved by binary search)
     const uint32_t *cells;       // level l occupies [cell_off(l), cell_off(l) + 8^l] (8^l + 1 entries)
+    const uint64_t *cbox;        // level l occupies [box_off(l), box_off(l) + 8^l): occupied 1/1024 slices of each non-empty cell
     int lmax;                    // finest level
     float glo[3], gext;          // cubic quantisation grid: fine index = (p - glo) / gext * 2^21
     double gu;                   // size of a fine unit: gext / 2^21
 };
 __host__ __device__ inline long long cell_off(int l) { return (((1LL << (3 * l)) - 1) / 7) + l; }
+__host__ __device__ inline long long box_off(int l) { return ((1LL << (3 * l)) - 1) / 7; }
 
 // per-wave LDS working set
 struct KnnBuf {
@@ -417,21 +419,31 @@ __device__ inline void photon_term(const float4 &pp, const uint4 &rr, const V3 &
 #ifndef PM_USE_GRID
 #define PM_USE_GRID 1
 #endif
-__device__ inline int grid_query(KnnState &st, KnnBuf *buf, const MapView &m, const V3 &q, double &r);   // pm_grid.h
+__device__ inline int grid_query(KnnState &st, KnnBuf *buf, const MapView &m, const V3 &q, double &r, double lim0);   // pm_grid.h
 #if PM_USE_GRID
-#define KNN_QUERY grid_query
+#define KNN_QUERY(st, buf, m, p, r, lim0) grid_query(st, buf, m, p, r, lim0)
 #else
-#define KNN_QUERY knn_query
+#define KNN_QUERY(st, buf, m, p, r, lim0) knn_query(st, buf, m, p, r)
 #endif
 
 constexpr double FX_SCALE = 72057594037927936.0;   // 2^56
 
+// A run of neighbouring queries hands the ball of one query to the next: 63 photons lie within sqrt(r) of `at`.
+struct KnnCarry { V3 at; double r; bool full; };
+__device__ inline double carry_bound(const KnnCarry &c, const V3 &p) {
+    if (!c.full) return MAX_R2;
+    double dx = p.x - c.at.x, dy = p.y - c.at.y, dz = p.z - c.at.z;
+    double reach = sqrt(c.r) + sqrt(dx * dx + dy * dy + dz * dz);
+    return reach * reach * (1.0 + 1e-12) + 1e-300;   // rounded up: the collection test is '<'
+}
+
 // query + radiance estimate; result valid in every lane
 template <int KIND>
-__device__ inline void knn_gather(KnnBuf *buf, const MapView &m, const V3 &p, const V3 &nrm, double &R, double &G, double &B) {
+__device__ inline void knn_gather(KnnBuf *buf, const MapView &m, const V3 &p, const V3 &nrm, double &R, double &G, double &B, KnnCarry &carry) {
     KnnState st;
     double r;
-    int found = KNN_QUERY(st, buf, m, p, r);
+    int found = KNN_QUERY(st, buf, m, p, r, carry_bound(carry, p));
+    carry.at = p; carry.r = r; carry.full = found == KNN_K;
     R = G = B = 0.0;
     if (found == 0) return;
     if (st.lane < 3) buf->acc[st.lane] = 0ULL;
