@@ -60,7 +60,9 @@ struct pm_ctx {
     DevBuf scene;
     SceneView gv{};
     // frame work buffers (grow only, reused across frames)
-    DevBuf geo, obj, pixel, node, tabslot, direct, radg, radc, color, clist, tab, ctr, pane, sched;
+    DevBuf geo, obj, pixel, node, tabslot, direct, radg, radc, color, clist, tab, ctr, pane, sched, groups, left, strips;
+    bool use_tiles = true;     // PM_GATHER_TILE=0: every shade point goes through the per-query kernel (A/B switch)
+    int tile_blocks = 0, query_blocks = 0;   // resident blocks of the two gather kernels on this device
     uint32_t sp_cap = 0;
     Counters *h_ctr = nullptr;   // pinned
     uint64_t *h_u64 = nullptr;   // pinned scratch (2 words)
@@ -106,7 +108,7 @@ extern "C" int pm_ctx_destroy(pm_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->scene, &ctx->geo, &ctx->obj, &ctx->pixel, &ctx->node, &ctx->tabslot, &ctx->direct, &ctx->radg, &ctx->radc,
-                      &ctx->color, &ctx->clist, &ctx->tab, &ctx->ctr, &ctx->pane, &ctx->sched, &ctx->emit_tmp, &ctx->emit_flag, &ctx->emit_counts,
+                      &ctx->color, &ctx->clist, &ctx->tab, &ctx->ctr, &ctx->pane, &ctx->sched, &ctx->groups, &ctx->left, &ctx->strips, &ctx->emit_tmp, &ctx->emit_flag, &ctx->emit_counts,
                       &ctx->emit_offs, &ctx->emit_out, &ctx->keys_in, &ctx->keys_out, &ctx->vals_in, &ctx->vals_out, &ctx->sort_tmp, &ctx->bounds};
     for (DevBuf *b : bufs) b->release();
     if (ctx->h_ctr) (void)hipHostFree(ctx->h_ctr);
@@ -490,6 +492,25 @@ static SPQueue sp_queue(pm_ctx *ctx) {
     return q;
 }
 
+// resident blocks of the gather kernels (they are persistent: work comes from device counters), a multiple of 8 so that
+// every XCD gets the same number
+static int gather_blocks(pm_ctx *ctx) {
+    if (ctx->tile_blocks) return PM_OK;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
+    int per_cu_t = 0, per_cu_q = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_t, k_gather_tile<0>, 64, 0));
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_q, k_gather<0>, 256, 0));
+    int cus = std::max(8, prop.multiProcessorCount);
+    ctx->tile_blocks = std::max(8, std::max(1, per_cu_t) * cus / 8 * 8);
+    ctx->query_blocks = std::max(8, std::max(1, per_cu_q) * cus / 8 * 8);
+    const char *e = getenv("PM_GATHER_TILE");
+    ctx->use_tiles = !(e && e[0] == '0');
+    if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] resident gather blocks: group kernel %d (%d per CU), per-query kernel %d (%d per CU), %d CUs\n", ctx->tile_blocks, per_cu_t,
+                                    ctx->query_blocks, per_cu_q, cus);
+    return PM_OK;
+}
+
 extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_params *rp, uint32_t *pane, int32_t pane_on_device,
                          pm_stats *stats) {
     FrameParams fp;
@@ -510,6 +531,7 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
     if (!pane_on_device) { PMCHK(ctx->pane.ensure((size_t)W * H * 4)); d_pane = ctx->pane.as<uint32_t>(); }
     PMCHK(ctx->ctr.ensure(sizeof(Counters)));
     PMCHK(ctx->clist.ensure(owned_px * 4));
+    PMCHK(ctx->groups.ensure((owned_px / 64 + 1) * sizeof(uint2)));   // one group per 8x8 pixel tile
     PMCHK(ensure_sp(ctx, (uint32_t)std::min<size_t>(owned_px + owned_px / 4, 0xFFFFFF00u)));
     Counters *d_ctr = ctx->ctr.as<Counters>();
     dim3 grid_px((W + 15) / 16, owned), block(256);
@@ -519,7 +541,7 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
     for (int attempt = 0; attempt < 2; attempt++) {
         HIPCHK(hipMemsetAsync(d_ctr, 0, sizeof(Counters), ctx->stream));
         SPQueue q = sp_queue(ctx);
-        LAUNCH_SCENE(k_primary, grid_px, block, ctx, fp, d_pane, d_ctr, q, ctx->clist.as<uint32_t>());
+        LAUNCH_SCENE(k_primary, grid_px, block, ctx, fp, d_pane, d_ctr, q, ctx->clist.as<uint32_t>(), ctx->groups.as<uint2>());
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(ctx->h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -547,14 +569,34 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
     if (n_sp) {
         LAUNCH_SCENE(k_shadow, dim3((n_sp + 255) / 256), block, ctx, fp, q, n_sp);
         HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
-        unsigned blocks; uint32_t waves;
-        gather_grid(n_sp, blocks, waves);
-        PMCHK(ctx->sched.ensure(2 * SCHED_WORDS * 4 + 2 * 8192 * 16));
-        HIPCHK(hipMemsetAsync(ctx->sched.p, 0, 2 * SCHED_WORDS * 4, ctx->stream));   // 64 work counters per gather launch
-        if (!(rp->flags & PM_FLAG_NO_GLOBAL)) { hipLaunchKernelGGL(k_gather<0>, dim3(blocks), block, 0, ctx->stream, gmap->view, q, n_sp, ctx->sched.as<uint32_t>()); n_gathers++; }
-        HIPCHK(hipEventRecord(ctx->ev[4], ctx->stream));
-        if (!(rp->flags & PM_FLAG_NO_CAUSTIC)) { hipLaunchKernelGGL(k_gather<1>, dim3(blocks), block, 0, ctx->stream, cmap->view, q, n_sp, ctx->sched.as<uint32_t>() + SCHED_WORDS); n_gathers++; }
-        HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));
+        // The gather: groups of neighbouring shade points first (k_gather_tile), then one wave per shade point for what
+        // the group kernel left and for the shade points of bounced pixels (k_gather).  Both kernels are launched with
+        // as many blocks as the device keeps resident and draw their work from device counters.
+        PMCHK(gather_blocks(ctx));
+        PMCHK(ctx->sched.ensure(4 * SCHED_WORDS * 4 + 2 * 8192 * 16));
+        PMCHK(ctx->left.ensure((size_t)2 * n_sp0 * 4 + 8));
+        PMCHK(ctx->strips.ensure((size_t)ctx->tile_blocks * TS_STRIDE * sizeof(float4)));
+        HIPCHK(hipMemsetAsync(ctx->sched.p, 0, 4 * SCHED_WORDS * 4, ctx->stream));   // 64 work counters per gather launch
+        uint32_t *sched = ctx->sched.as<uint32_t>();
+        uint32_t *left = ctx->left.as<uint32_t>();
+        const bool use_tiles = ctx->use_tiles && n_sp0 > 0;
+        const int dbg = getenv("PM_DEBUG") ? 1 : 0;
+        // without the group kernel every shade point is in the per-query kernel's range: it simply starts at 0
+        const uint32_t sec_lo = use_tiles ? n_sp0 : 0u, sec_n = n_sp - sec_lo;
+        for (int kind = 0; kind < 2; kind++) {
+            pm_map *map = kind == 0 ? gmap : cmap;
+            if (rp->flags & (kind == 0 ? PM_FLAG_NO_GLOBAL : PM_FLAG_NO_CAUSTIC)) { HIPCHK(hipEventRecord(ctx->ev[4 + kind], ctx->stream)); continue; }
+            uint32_t *lk = left + (size_t)kind * n_sp0, *nl = &d_ctr->n_left[kind];
+            if (kind == 0) {
+                if (use_tiles) hipLaunchKernelGGL(k_gather_tile<0>, dim3(ctx->tile_blocks), dim3(64), 0, ctx->stream, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sched, ctx->strips.as<float4>(), dbg);
+                hipLaunchKernelGGL(k_gather<0>, dim3(ctx->query_blocks), block, 0, ctx->stream, map->view, q, lk, nl, sec_lo, sec_n, sched + SCHED_WORDS);
+            } else {
+                if (use_tiles) hipLaunchKernelGGL(k_gather_tile<1>, dim3(ctx->tile_blocks), dim3(64), 0, ctx->stream, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sched + 2 * SCHED_WORDS, ctx->strips.as<float4>(), dbg);
+                hipLaunchKernelGGL(k_gather<1>, dim3(ctx->query_blocks), block, 0, ctx->stream, map->view, q, lk, nl, sec_lo, sec_n, sched + 3 * SCHED_WORDS);
+            }
+            n_gathers++;
+            HIPCHK(hipEventRecord(ctx->ev[4 + kind], ctx->stream));
+        }
         LAUNCH_SCENE(k_shade, dim3((n_sp + 255) / 256), block, ctx, fp, q, n_sp, d_pane, tab);
     } else {
         for (int i = 3; i <= 5; i++) HIPCHK(hipEventRecord(ctx->ev[i], ctx->stream));
@@ -569,10 +611,20 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
         }
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (getenv("PM_DEBUG")) {
+        Counters hc;
+        if (hipMemcpy(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "[pm] shade points %u (primary %u), groups %u, left to the per-query gather: global %u caustic %u\n", hc.n_sp, n_sp0,
+                    hc.n_groups, hc.n_left[0], hc.n_left[1]);
+        fprintf(stderr, "[pm] lanes handed over, by reason (few photons, spread, radius, |S|, no lane served, -, own shortfall): %u %u %u %u %u %u %u\n", hc.why[1], hc.why[2],
+                hc.why[3], hc.why[4], hc.why[5], hc.why[6], hc.why[7]);
+        fprintf(stderr, "[pm] group kernel ticks per phase (centre query, collect, pass 1, pass 2, rank, sum): %llu %llu %llu %llu %llu %llu; shared sets %llu, candidates %llu\n", hc.tphase[0],
+                hc.tphase[1], hc.tphase[2], hc.tphase[3], hc.tphase[4], hc.tphase[5], hc.tphase[7], hc.tphase[6]);
+    }
 #ifdef PM_WAVE_TIMES
     if (const char *path = getenv("PM_WAVE_DUMP")) {
         std::vector<uint32_t> h(2 * 8192 * 4);
-        if (n_sp && hipMemcpy(h.data(), ctx->sched.as<uint32_t>() + 2 * SCHED_WORDS, h.size() * 4, hipMemcpyDeviceToHost) == hipSuccess)
+        if (n_sp && hipMemcpy(h.data(), ctx->sched.as<uint32_t>() + 4 * SCHED_WORDS, h.size() * 4, hipMemcpyDeviceToHost) == hipSuccess)
             if (FILE *f = fopen(path, "wb")) { fwrite(h.data(), 4, h.size(), f); fclose(f); }
     }
 #endif

@@ -64,12 +64,12 @@ __device__ inline uint64_t cell_key(int level, uint32_t cx, uint32_t cy, uint32_
     return morton63(cx, cy, cz);
 }
 
-// squared distances from q to the nearest and the farthest point of the box of cell (cx,cy,cz) of `level`: the occupied
-// slices of the cell where the map stores them (table levels), the whole cube below; either way grown by the
-// two-fine-unit binning margin (photons were binned with float arithmetic).  dmin2 is never above, dmax2 never below
-// the d2 of a photon filed in the cell.
-__device__ inline void cell_d2(const MapView &m, const V3 &q, int level, uint32_t cx, uint32_t cy, uint32_t cz, uint64_t key, bool boxed,
-                               double &dmin2, double &dmax2) {
+// squared distances from the query box [qlo, qhi] (a point when both are equal) to the nearest and the farthest point of
+// the box of cell (cx,cy,cz) of `level`: the occupied slices of the cell where the map stores them (table levels), the
+// whole cube below; either way grown by the two-fine-unit binning margin (photons were binned with float arithmetic).
+// dmin2 is never above, dmax2 never below the d2 of a photon filed in the cell (dmax2 is meant for point queries).
+__device__ inline void cell_d2(const MapView &m, const V3 &qlo, const V3 &qhi, int level, uint32_t cx, uint32_t cy, uint32_t cz, uint64_t key,
+                               bool boxed, double &dmin2, double &dmax2) {
     const int sh = 21 - level;
     uint32_t lo_s[3] = {0u, 0u, 0u}, hi_s[3] = {1u << sh, 1u << sh, 1u << sh};   // in fine units from the cell's corner
     if (boxed) {   // level <= lmax <= 8: a slice is 2^(sh-10) >= 8 fine units
@@ -84,11 +84,11 @@ __device__ inline void cell_d2(const MapView &m, const V3 &q, int level, uint32_
     const uint32_t cc[3] = {cx, cy, cz};
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        double qa = a == 0 ? q.x : (a == 1 ? q.y : q.z);
+        double ql = a == 0 ? qlo.x : (a == 1 ? qlo.y : qlo.z), qh = a == 0 ? qhi.x : (a == 1 ? qhi.y : qhi.z);
         uint32_t o = cc[a] << sh;
         double lo_face = (double)m.glo[a] + ((double)(o + lo_s[a]) - 2.0) * m.gu, hi_face = (double)m.glo[a] + ((double)(o + hi_s[a]) + 2.0) * m.gu;
-        double gap = qa < lo_face ? lo_face - qa : (qa > hi_face ? qa - hi_face : 0.0);
-        double far = fmax(fabs(qa - lo_face), fabs(hi_face - qa));
+        double gap = qh < lo_face ? lo_face - qh : (ql > hi_face ? ql - hi_face : 0.0);
+        double far = fmax(fabs(ql - lo_face), fabs(hi_face - qh));
         dmin2 += gap * gap;
         dmax2 += far * far;
     }
@@ -193,7 +193,7 @@ __device__ inline int grid_query(KnnState &st, KnnBuf *buf, const MapView &m, co
         cz = (lev ? qf[2] >> sh : 0u) ^ (uint32_t)(j >> 2);
         uint64_t key = cell_key(lev, cx, cy, cz);
         cell_range(m, lev, key, 0u, 0u, first, cnt);
-        if (cnt > 0) cell_d2(m, q, lev, cx, cy, cz, key, true, dmin2, dmax2);
+        if (cnt > 0) cell_d2(m, q, q, lev, cx, cy, cz, key, true, dmin2, dmax2);
     }
     for (;;) {
         if (fresh_cells) {
@@ -253,7 +253,7 @@ __device__ inline int grid_query(KnnState &st, KnnBuf *buf, const MapView &m, co
                     cx = 2 * px + (uint32_t)(cj & 1); cy = 2 * py + (uint32_t)((cj >> 1) & 1); cz = 2 * pz + (uint32_t)(cj >> 2);
                     uint64_t key = cell_key(lev, cx, cy, cz);
                     cell_range(m, lev, key, pfirst, pfirst + pcnt, first, cnt);
-                    if (cnt > 0) cell_d2(m, q, lev, cx, cy, cz, key, lev <= m.lmax, dmin2, dmax2);
+                    if (cnt > 0) cell_d2(m, q, q, lev, cx, cy, cz, key, lev <= m.lmax, dmin2, dmax2);
                 }
                 fresh_cells = true;
                 PM_LAP(t_node)

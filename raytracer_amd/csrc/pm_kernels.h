@@ -13,6 +13,7 @@
 #include "pm_device.h"
 #include "pm_knn.h"
 #include "pm_grid.h"
+#include "pm_tile.h"
 
 namespace pm {
 
@@ -25,7 +26,7 @@ struct FrameParams {
     int rank, world;
 };
 
-struct Counters { uint32_t n_sp, n_complex, n_secondary, pad; };
+struct Counters { uint32_t n_sp, n_complex, n_secondary, n_groups, n_left[2], pad[2]; uint32_t why[8]; unsigned long long tphase[8]; };   // n_left[k]: shade points left to the per-query gather of map k
 
 // shade point queue (SoA)
 struct SPQueue {
@@ -78,7 +79,7 @@ __device__ inline bool tile_pixel(const FrameParams &fp, int &x, int &y) {
 }
 
 template <bool LDS>
-__global__ __launch_bounds__(256) void k_primary(SceneView gs, FrameParams fp, uint32_t *pane, Counters *ctr, SPQueue q, uint32_t *complex_list) {
+__global__ __launch_bounds__(256) void k_primary(SceneView gs, FrameParams fp, uint32_t *pane, Counters *ctr, SPQueue q, uint32_t *complex_list, uint2 *groups) {
     extern __shared__ __align__(16) unsigned char smem[];
     SceneView sv = gs;
     if (LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
@@ -105,7 +106,10 @@ __global__ __launch_bounds__(256) void k_primary(SceneView gs, FrameParams fp, u
     if (m) {
         int leader = __ffsll((long long)m) - 1;
         uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&ctr->n_sp, (uint32_t)__popcll(m));
+        if (lane == leader) {
+            base = atomicAdd(&ctr->n_sp, (uint32_t)__popcll(m));
+            groups[atomicAdd(&ctr->n_groups, 1u)] = make_uint2(base, (uint32_t)__popcll(m));   // the tile's shade points: one gather group
+        }
         base = __shfl(base, leader);
         if (emit_sp) sp_store(q, base + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL)), res, nrm, obj, pixel, 1u, 0u);
     }
@@ -279,38 +283,54 @@ __device__ __noinline__ uint32_t wave_draw(uint32_t *ctr) {
 #ifndef PM_GATHER_GROUP
 #define PM_GATHER_GROUP 4      // consecutive shade points (neighbouring pixels) per draw
 #endif
-constexpr uint32_t SCHED_CHUNK = 1024;   // shade points per chunk; chunk c belongs to counter c % 64
+constexpr uint32_t SCHED_CHUNK = 1024;   // items per chunk; chunk c belongs to counter c % 64
 constexpr uint32_t SCHED_STRIDE = 32;    // one counter per 128-byte line
 constexpr uint32_t SCHED_WORDS = 64 * SCHED_STRIDE;
 static_assert(SCHED_CHUNK % PM_GATHER_GROUP == 0, "a draw must not straddle two chunks");
-// One wave per shade point, work drawn from device counters.  The queue is cut into chunks of 1024 consecutive shade
-// points (a strip of the image, so a compact part of the photon map); chunk c is served by counter c % 64 and counter k
-// by the blocks of XCD k % 8 (blocks b, b+8, ... share an XCD and its L2).  A wave starts on one of its XCD's 8 counters
-// and moves to the next when that runs dry, so a cluster of expensive queries never becomes one wave's tail and no
-// counter sees more than a few thousand draws.
+// Work distribution of the gather kernels: items are cut into chunks of SCHED_CHUNK consecutive items (a strip of the
+// image, so a compact part of the photon map); chunk c is served by counter c % 64 and counter k by the blocks of XCD
+// k % 8 (blocks b, b+8, ... share an XCD and its L2).  A wave starts on one of its XCD's 8 counters and moves to the next
+// when that runs dry, so a cluster of expensive items never becomes one wave's tail and no counter sees more than a few
+// thousand draws.  Returns false when all 8 counters are exhausted; else [i0, i1) is a run of up to `group` items.
+struct WorkDraw {
+    uint32_t xcd, sub, tries;
+    __device__ WorkDraw() : xcd(blockIdx.x & 7), sub((blockIdx.x >> 3) & 7), tries(0) {}
+    __device__ bool next(uint32_t *sched, uint32_t n_items, uint32_t group, uint32_t &i0, uint32_t &i1) {
+        while (tries < 8) {
+            const uint32_t c = xcd + 8 * sub;
+            uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_draw(&sched[c * SCHED_STRIDE]));
+            uint32_t li = g * group;
+            uint64_t s0 = ((uint64_t)c + 64ull * (li / SCHED_CHUNK)) * SCHED_CHUNK + li % SCHED_CHUNK;
+            if (s0 >= n_items) { tries++; sub = (sub + 1) & 7; continue; }   // this counter is exhausted (s0 grows with every draw)
+            i0 = (uint32_t)s0;
+            i1 = i0 + group < n_items ? i0 + group : n_items;
+            return true;
+        }
+        return false;
+    }
+};
+
+// One wave per shade point (pm_grid.h).  Items are the shade points the group kernel left: `left[0 .. *n_left)`, then the
+// slots [sec_lo, sec_lo + sec_n) of the bounced pixels' shade points, which come in no spatial order at all.
 template <int KIND>
-__global__ __launch_bounds__(256) void k_gather(MapView m, SPQueue q, uint32_t n_sp, uint32_t *sched) {
+__global__ __launch_bounds__(256) void k_gather(MapView m, SPQueue q, const uint32_t *left, const uint32_t *n_left, uint32_t sec_lo, uint32_t sec_n,
+                                                uint32_t *sched) {
     __shared__ KnnBuf bufs[4];
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler should know
     KnnBuf *buf = &bufs[wave_in_block];
     int lane = threadIdx.x & 63;
     double *out = KIND == 0 ? q.rad_g : q.rad_c;
-    const uint32_t xcd = blockIdx.x & 7;
-    uint32_t sub = (blockIdx.x >> 3) & 7;
+    const uint32_t nl = *n_left, n_items = nl + sec_n;
+    WorkDraw wd;
 #ifdef PM_WAVE_TIMES
     unsigned long long wt0 = __builtin_amdgcn_s_memtime(); uint32_t wq = 0;
 #endif
-    for (uint32_t tries = 0; tries < 8;) {
-        const uint32_t c = xcd + 8 * sub;
-        uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_draw(&sched[c * SCHED_STRIDE]));
-        uint32_t li = g * (uint32_t)PM_GATHER_GROUP;
-        uint64_t s0 = ((uint64_t)c + 64ull * (li / SCHED_CHUNK)) * SCHED_CHUNK + li % SCHED_CHUNK;
-        if (s0 >= n_sp) { tries++; sub = (sub + 1) & 7; continue; }   // this counter is exhausted (s0 grows with every draw)
-        uint32_t s1 = (uint32_t)s0 + (uint32_t)PM_GATHER_GROUP;
-        if (s1 > n_sp) s1 = n_sp;
+    uint32_t i0, i1;
+    while (wd.next(sched, n_items, (uint32_t)PM_GATHER_GROUP, i0, i1)) {
         KnnCarry carry;
         carry.full = false;
-        for (uint32_t s = (uint32_t)s0; s < s1; s++) {
+        for (uint32_t i = i0; i < i1; i++) {
+            const uint32_t s = i < nl ? left[i] : sec_lo + (i - nl);
             V3 p = {q.geo[0 * (size_t)q.cap + s], q.geo[1 * (size_t)q.cap + s], q.geo[2 * (size_t)q.cap + s]};
             V3 nrm = {q.geo[3 * (size_t)q.cap + s], q.geo[4 * (size_t)q.cap + s], q.geo[5 * (size_t)q.cap + s]};
             double R, G, B;
@@ -326,10 +346,81 @@ __global__ __launch_bounds__(256) void k_gather(MapView m, SPQueue q, uint32_t n
     if (lane == 0) {
         uint32_t w = blockIdx.x * 4 + wave_in_block;
         unsigned long long wt1 = __builtin_amdgcn_s_memtime();
-        uint32_t *o = sched + 2 * SCHED_WORDS + (size_t)KIND * 8192 * 4 + (size_t)w * 4;
-        o[0] = (uint32_t)wt0; o[1] = (uint32_t)wt1; o[2] = wq; o[3] = xcd;
+        uint32_t *o = sched + 4 * SCHED_WORDS + (size_t)KIND * 8192 * 4 + (size_t)w * 4;
+        o[0] = (uint32_t)wt0; o[1] = (uint32_t)wt1; o[2] = wq; o[3] = wd.xcd;
     }
 #endif
+}
+
+// One wave per GROUP of shade points (pm_tile.h): the shade points of one 8x8 pixel tile, one per lane.  A group that
+// cannot be gathered as a group appends its slots to `left` for k_gather.
+template <int KIND>
+__global__ __launch_bounds__(64) void k_gather_tile(MapView m, SPQueue q, const uint2 *groups, const Counters *ctr, uint32_t *left, uint32_t *n_left,
+                                                    uint32_t *sched, float4 *strips, int dbg) {
+    __shared__ TileBuf tb;
+    const int lane = threadIdx.x;
+    const Strip S(reinterpret_cast<float *>(strips + (size_t)blockIdx.x * TS_STRIDE));   // this wave's strip for the shared candidate set
+    double *out = KIND == 0 ? q.rad_g : q.rad_c;
+    const uint32_t n_groups = ctr->n_groups;
+    WorkDraw wd;
+    uint32_t i0, i1;
+    while (wd.next(sched, n_groups, 1u, i0, i1)) {
+        const uint2 g = groups[i0];
+        const bool active = (uint32_t)lane < g.y;
+        const uint32_t s = g.x + (active ? (uint32_t)lane : 0u);
+        const V3 p = {q.geo[0 * (size_t)q.cap + s], q.geo[1 * (size_t)q.cap + s], q.geo[2 * (size_t)q.cap + s]};
+        const V3 nrm = {q.geo[3 * (size_t)q.cap + s], q.geo[4 * (size_t)q.cap + s], q.geo[5 * (size_t)q.cap + s]};
+        // The whole group first; a part too spread out for one shared set is cut in two across the longest side of its
+        // bounding box (three times at most) and the pieces are served one after the other.  todo: not answered yet;
+        // dead: goes to the per-query kernel; pid / pdepth: the piece a lane belongs to and how often it was cut.
+        bool todo = active, dead = false;
+        int pid = 0, pdepth = 0, npieces = 1;
+        double r_scale = 0.0;
+        int why = 0;
+        for (int round = 0; round < 16; round++) {
+            const unsigned long long tmask = __ballot(todo);
+            if (tmask == 0ULL) break;
+            const int cur = __builtin_amdgcn_readlane(pid, __ffsll((long long)tmask) - 1);   // any piece that is still open
+            const bool part = todo && pid == cur;
+            const unsigned long long pmask = __ballot(part);
+            // idle lanes repeat the piece's first point: the bounding box is that of the piece
+            const int f = __ffsll((long long)pmask) - 1;
+            const V3 pf = {__shfl(p.x, f), __shfl(p.y, f), __shfl(p.z, f)};   // (every lane must take part in the exchange)
+            const V3 pe = part ? p : pf;
+            double R, G, B;
+            const bool ok = tile_gather<KIND>(&tb, S, m, pe, nrm, part, r_scale, R, G, B, why, const_cast<unsigned long long *>(ctr->tphase));
+            if ((why == 2 || why == 4) && __builtin_amdgcn_readlane(pdepth, f) < 3 && __popcll(pmask) > 1) {
+                const V3 lo = {wave_min_f64(pe.x), wave_min_f64(pe.y), wave_min_f64(pe.z)}, hi = {wave_max_f64(pe.x), wave_max_f64(pe.y), wave_max_f64(pe.z)};
+                const double ex = hi.x - lo.x, ey = hi.y - lo.y, ez = hi.z - lo.z;
+                const bool low = ex >= ey && ex >= ez ? p.x <= 0.5 * (lo.x + hi.x) : (ey >= ez ? p.y <= 0.5 * (lo.y + hi.y) : p.z <= 0.5 * (lo.z + hi.z));
+                if (part) { pdepth++; if (!low) pid = npieces; }
+                npieces++;
+                continue;
+            }
+            if (why != 0) { if (part) dead = true; }        // nothing was computed for this piece
+            else if (part) {
+                if (ok) { out[0 * (size_t)q.cap + s] = R; out[1 * (size_t)q.cap + s] = G; out[2 * (size_t)q.cap + s] = B; }
+                else dead = true;
+            }
+            if (dbg) {   // diagnostic: lanes handed over, by reason (7 = the lane's own shortfall)
+                const int lost = __popcll(__ballot(part && (why != 0 || !ok)));
+                if (lane == 0 && lost) atomicAdd(const_cast<uint32_t *>(&ctr->why[why != 0 ? (why & 7) : 7]), (uint32_t)lost);
+            }
+            if (part) todo = false;
+        }
+#ifdef PM_TILE_PRINT
+        { int nt = __popcll(__ballot(todo)), nd = __popcll(__ballot(dead));
+          if (lane == 0 && (i0 % 61) == 0 && KIND == 0) printf("group %u n %u pieces %d still-open %d dead %d last why %d\n", i0, g.y, npieces, nt, nd, why); }
+#endif
+        if (todo) dead = true;
+        const unsigned long long lm = __ballot(dead);
+        if (lm) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(n_left, (uint32_t)__popcll(lm));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (dead) left[base + (uint32_t)lane_rank(lm)] = s;
+        }
+    }
 }
 
 // standalone gather on caller-provided points (pm_knn_gather): points/normals/radiance are [m][3]
