@@ -53,6 +53,8 @@ constexpr int N_EVENTS = 8;
 struct pm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux = nullptr;           // the caustic gather runs beside the global one
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // scene
     int nprims = 0, stride = 0;
     bool lds = true;
@@ -99,6 +101,9 @@ extern "C" int pm_ctx_create(int device, pm_ctx **out) {
     HIPCHK(hipHostMalloc((void **)&ctx->h_ctr, sizeof(Counters), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&ctx->h_u64, 4 * sizeof(uint64_t), hipHostMallocDefault));
     for (int i = 0; i < N_EVENTS; i++) HIPCHK(hipEventCreate(&ctx->ev[i]));
+    HIPCHK(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     *out = ctx;
     return PM_OK;
 }
@@ -114,6 +119,9 @@ extern "C" int pm_ctx_destroy(pm_ctx *ctx) {
     if (ctx->h_ctr) (void)hipHostFree(ctx->h_ctr);
     if (ctx->h_u64) (void)hipHostFree(ctx->h_u64);
     for (int i = 0; i < N_EVENTS; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     delete ctx;
     return PM_OK;
 }
@@ -575,7 +583,7 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
         PMCHK(gather_blocks(ctx));
         PMCHK(ctx->sched.ensure(4 * SCHED_WORDS * 4 + 2 * 8192 * 16));
         PMCHK(ctx->left.ensure((size_t)2 * n_sp0 * 4 + 8));
-        PMCHK(ctx->strips.ensure((size_t)ctx->tile_blocks * TS_STRIDE * sizeof(float4)));
+        PMCHK(ctx->strips.ensure((size_t)2 * ctx->tile_blocks * TS_STRIDE * sizeof(float4)));
         HIPCHK(hipMemsetAsync(ctx->sched.p, 0, 4 * SCHED_WORDS * 4, ctx->stream));   // 64 work counters per gather launch
         uint32_t *sched = ctx->sched.as<uint32_t>();
         uint32_t *left = ctx->left.as<uint32_t>();
@@ -583,20 +591,29 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
         const int dbg = getenv("PM_DEBUG") ? 1 : 0;
         // without the group kernel every shade point is in the per-query kernel's range: it simply starts at 0
         const uint32_t sec_lo = use_tiles ? n_sp0 : 0u, sec_n = n_sp - sec_lo;
+        // The two maps are gathered side by side: the global map on the caller's stream, the caustic map on the context's
+        // second stream, so that the thin end of one launch (few groups left, most CUs idle) is filled by the other.
+        HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+        HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
         for (int kind = 0; kind < 2; kind++) {
             pm_map *map = kind == 0 ? gmap : cmap;
-            if (rp->flags & (kind == 0 ? PM_FLAG_NO_GLOBAL : PM_FLAG_NO_CAUSTIC)) { HIPCHK(hipEventRecord(ctx->ev[4 + kind], ctx->stream)); continue; }
+            if (rp->flags & (kind == 0 ? PM_FLAG_NO_GLOBAL : PM_FLAG_NO_CAUSTIC)) continue;
+            hipStream_t st = kind == 0 ? ctx->stream : ctx->aux;
             uint32_t *lk = left + (size_t)kind * n_sp0, *nl = &d_ctr->n_left[kind];
+            float4 *strips = ctx->strips.as<float4>() + (size_t)kind * ctx->tile_blocks * TS_STRIDE;
             if (kind == 0) {
-                if (use_tiles) hipLaunchKernelGGL(k_gather_tile<0>, dim3(ctx->tile_blocks), dim3(64), 0, ctx->stream, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sched, ctx->strips.as<float4>(), dbg);
-                hipLaunchKernelGGL(k_gather<0>, dim3(ctx->query_blocks), block, 0, ctx->stream, map->view, q, lk, nl, sec_lo, sec_n, sched + SCHED_WORDS);
+                if (use_tiles) hipLaunchKernelGGL(k_gather_tile<0>, dim3(ctx->tile_blocks), dim3(64), 0, st, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sched, strips, dbg);
+                hipLaunchKernelGGL(k_gather<0>, dim3(ctx->query_blocks), block, 0, st, map->view, q, lk, nl, sec_lo, sec_n, sched + SCHED_WORDS);
             } else {
-                if (use_tiles) hipLaunchKernelGGL(k_gather_tile<1>, dim3(ctx->tile_blocks), dim3(64), 0, ctx->stream, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sched + 2 * SCHED_WORDS, ctx->strips.as<float4>(), dbg);
-                hipLaunchKernelGGL(k_gather<1>, dim3(ctx->query_blocks), block, 0, ctx->stream, map->view, q, lk, nl, sec_lo, sec_n, sched + 3 * SCHED_WORDS);
+                if (use_tiles) hipLaunchKernelGGL(k_gather_tile<1>, dim3(ctx->tile_blocks), dim3(64), 0, st, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sched + 2 * SCHED_WORDS, strips, dbg);
+                hipLaunchKernelGGL(k_gather<1>, dim3(ctx->query_blocks), block, 0, st, map->view, q, lk, nl, sec_lo, sec_n, sched + 3 * SCHED_WORDS);
             }
             n_gathers++;
-            HIPCHK(hipEventRecord(ctx->ev[4 + kind], ctx->stream));
         }
+        HIPCHK(hipEventRecord(ctx->ev[4], ctx->stream));            // the global gather is done
+        HIPCHK(hipEventRecord(ctx->ev_join, ctx->aux));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));            // both are done
         LAUNCH_SCENE(k_shade, dim3((n_sp + 255) / 256), block, ctx, fp, q, n_sp, d_pane, tab);
     } else {
         for (int i = 3; i <= 5; i++) HIPCHK(hipEventRecord(ctx->ev[i], ctx->stream));

@@ -42,7 +42,7 @@ struct TileSel {
     uint16_t member[64 * TS_MROW];                 // [lane][k]
     uint16_t binl[TS_BINL * 64];                   // [k][lane]
 };
-struct TileBuf {
+struct alignas(16) TileBuf {
     union { KnnBuf knn; TileSel sel; };    // the centre query and the range walk are over before the selection starts
 };
 
@@ -52,7 +52,8 @@ __device__ inline double wave_max_f64(double v) { for (int s = 1; s < 64; s <<= 
 // The shared set of one wave, in its strip of device memory: photon positions RELATIVE to the centre of the group's
 // box, rounded to float (good to a few 1e-8: enough to sort photons into distance bins, never used for a result), and
 // the photons' indices.  One array per component so that two neighbouring candidates load as a register pair.
-constexpr int TS_STRIDE = TS_CAP + 4 * TS_BATCH;   // spare entries: the passes fetch whole batches ahead
+constexpr int TS_CHUNK = 128;                  // candidates staged in LDS at a time by the selection passes
+constexpr int TS_STRIDE = TS_CAP + TS_CHUNK;   // spare entries: the passes fetch whole chunks, the tail holds sentinels
 struct Strip {
     float *x, *y, *z;
     uint32_t *idx;
@@ -159,6 +160,9 @@ __device__ inline int tile_collect(TileBuf *tb, const Strip &S, const MapView &m
         }
         if (take) cnt = 0;
     }
+    // far-away sentinels behind the last candidate: the passes work in whole batches and need no index test
+#pragma unroll
+    for (int u = 0; u < TS_CHUNK / 64; u++) S.x[ns + u * 64 + lane] = 3.0e18f;
     // the strip is read back through the vector caches by this same wave: writes done, stale lines of the previous group dropped
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
     wave_lds_fence();
@@ -170,40 +174,48 @@ __device__ inline double tile_d2(const float4 &s, const V3 &p) {   // src/Photon
     return ddx * ddx + ddy * ddy + ddz * ddz;
 }
 
-// One pass over the shared set: fn(j, d2f) for every candidate j < ns, d2f its float squared distance to this lane's
-// point (relative coordinates).  Two batches of TS_BATCH candidates are in flight: the strip sits in the L2 (one
-// broadcast line per fetch) and a batch is fetched a whole batch of arithmetic before it is used.
+// One pass over the shared set: fn(j, d2f) for every candidate j < ns (and for some sentinels behind them, whose d2f is
+// astronomically large), d2f the float squared distance to this lane's point (relative coordinates).  The set is staged
+// through LDS TS_CHUNK candidates at a time -- the next chunk is on its way from the L2 while this one is consumed --
+// and read from there by all lanes at once (broadcast reads), TS_BATCH candidates per step.
+// stage: 2 * 3 * TS_CHUNK floats of LDS not otherwise in use during the pass.
 typedef float f2 __attribute__((ext_vector_type(2)));
-struct TileBatch { f2 x[TS_BATCH / 2], y[TS_BATCH / 2], z[TS_BATCH / 2]; };
-__device__ inline void tile_fetch(const Strip &S, int j0, TileBatch &b) {
-#pragma unroll
-    for (int u = 0; u < TS_BATCH / 2; u++) {
-        b.x[u] = *reinterpret_cast<const f2 *>(S.x + j0 + 2 * u);
-        b.y[u] = *reinterpret_cast<const f2 *>(S.y + j0 + 2 * u);
-        b.z[u] = *reinterpret_cast<const f2 *>(S.z + j0 + 2 * u);
-    }
-}
 template <class F>
-__device__ inline void tile_batch(const TileBatch &b, int j0, int ns, f2 px2, f2 py2, f2 pz2, F &fn) {
-#pragma unroll
-    for (int u = 0; u < TS_BATCH / 2; u++) {
-        f2 dx = b.x[u] - px2, dy = b.y[u] - py2, dz = b.z[u] - pz2;
-        f2 d2f = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-        if (j0 + 2 * u < ns) fn(j0 + 2 * u, d2f[0]);
-        if (j0 + 2 * u + 1 < ns) fn(j0 + 2 * u + 1, d2f[1]);
-    }
-}
-template <class F>
-__device__ inline void tile_pass(const Strip &S, int ns, float pxf, float pyf, float pzf, F fn) {
+__device__ inline void tile_pass(float *stage, const Strip &S, int ns, float pxf, float pyf, float pzf, F fn) {
+    static_assert(TS_CHUNK == 128 && TS_BATCH == 8, "two candidates per lane and chunk; batches of eight");
+    const int lane = threadIdx.x & 63;
     const f2 px2 = {pxf, pxf}, py2 = {pyf, pyf}, pz2 = {pzf, pzf};
-    TileBatch a, b;
-    tile_fetch(S, 0, a);
-    for (int j0 = 0; j0 < ns; j0 += 2 * TS_BATCH) {   // (the strip has spare entries: fetches may run past ns)
-        tile_fetch(S, j0 + TS_BATCH, b);
-        tile_batch(a, j0, ns, px2, py2, pz2, fn);
-        tile_fetch(S, j0 + 2 * TS_BATCH, a);
-        tile_batch(b, j0 + TS_BATCH, ns, px2, py2, pz2, fn);
+    const int nch = (ns + TS_CHUNK - 1) / TS_CHUNK;
+    f2 rx = *reinterpret_cast<const f2 *>(S.x + 2 * lane), ry = *reinterpret_cast<const f2 *>(S.y + 2 * lane), rz = *reinterpret_cast<const f2 *>(S.z + 2 * lane);
+    for (int c = 0; c < nch; c++) {
+        float *b = stage + (c & 1) * 3 * TS_CHUNK;
+        *reinterpret_cast<f2 *>(b + 2 * lane) = rx;
+        *reinterpret_cast<f2 *>(b + TS_CHUNK + 2 * lane) = ry;
+        *reinterpret_cast<f2 *>(b + 2 * TS_CHUNK + 2 * lane) = rz;
+        wave_lds_fence();
+        if (c + 1 < nch) {
+            const int o = (c + 1) * TS_CHUNK + 2 * lane;
+            rx = *reinterpret_cast<const f2 *>(S.x + o); ry = *reinterpret_cast<const f2 *>(S.y + o); rz = *reinterpret_cast<const f2 *>(S.z + o);
+        }
+        const int jn = min(ns - c * TS_CHUNK, TS_CHUNK);
+        for (int j0 = 0; j0 < jn; j0 += TS_BATCH) {
+            const float4 xa = *reinterpret_cast<const float4 *>(b + j0), xb = *reinterpret_cast<const float4 *>(b + j0 + 4);
+            const float4 ya = *reinterpret_cast<const float4 *>(b + TS_CHUNK + j0), yb = *reinterpret_cast<const float4 *>(b + TS_CHUNK + j0 + 4);
+            const float4 za = *reinterpret_cast<const float4 *>(b + 2 * TS_CHUNK + j0), zb = *reinterpret_cast<const float4 *>(b + 2 * TS_CHUNK + j0 + 4);
+            const f2 x[4] = {{xa.x, xa.y}, {xa.z, xa.w}, {xb.x, xb.y}, {xb.z, xb.w}};
+            const f2 y[4] = {{ya.x, ya.y}, {ya.z, ya.w}, {yb.x, yb.y}, {yb.z, yb.w}};
+            const f2 z[4] = {{za.x, za.y}, {za.z, za.w}, {zb.x, zb.y}, {zb.z, zb.w}};
+            const int j = c * TS_CHUNK + j0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                f2 dx = x[u] - px2, dy = y[u] - py2, dz = z[u] - pz2;
+                f2 d2f = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                fn(j + 2 * u, d2f[0]);
+                fn(j + 2 * u + 1, d2f[1]);
+            }
+        }
     }
+    wave_lds_fence();
 }
 
 // One group, or a part of it.  p, nrm: this lane's shade point; active: lane takes part (idle lanes must hold the point of
@@ -280,7 +292,7 @@ __device__ inline bool tile_gather(TileBuf *tb, const Strip &S, const MapView &m
     const float fscale = (float)TS_BINS / (float)L;
     const float Lq = active ? Lf : -1.0f;
     uint32_t n_in = 0;
-    tile_pass(S, ns, pxf, pyf, pzf, [&](int, float d2f) {
+    tile_pass(reinterpret_cast<float *>(sel.member), S, ns, pxf, pyf, pzf, [&](int, float d2f) {   // (the member lists are not in use yet)
         if (d2f < Lq) {
             int bin = min(TS_BINS - 1, (int)(d2f * fscale));
             atomicAdd(&sel.hist[(bin >> 2) * 64 + lane], 1u << (8 * (bin & 3)));
@@ -313,7 +325,7 @@ __device__ inline bool tile_gather(TileBuf *tb, const Strip &S, const MapView &m
     const float lo_t = ok ? __double2float_rd(lo_e - 2.0 * g) : -1.0f, hi_t = ok ? __double2float_ru(hi_e + 2.0 * g) : -1.0f;
     // pass 2: members for sure, list of the uncertain band
     int mc = 0, bc = 0;
-    tile_pass(S, ns, pxf, pyf, pzf, [&](int j, float d2f) {
+    tile_pass(reinterpret_cast<float *>(sel.hist), S, ns, pxf, pyf, pzf, [&](int j, float d2f) {   // (the histogram is done)
         // (the two counters are advanced outside the branches: merged into one conditional store they end up in memory)
         const bool sure = d2f < lo_t, band = !sure && d2f <= hi_t;
         if (sure) sel.member[lane * TS_MROW + mc] = (uint16_t)j;
