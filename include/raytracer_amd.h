@@ -81,9 +81,14 @@ typedef struct pm_stats {
     uint64_t gathers;              /* find_nearest_photons top-level calls */
     uint64_t absorb_points;
     uint64_t complex_pixels;       /* pixels whose primary hit reflects or refracts */
-    /* device time of each phase of the last call, from HIP events on the context's stream (ms) */
+    /* device time of each phase of the last call, from HIP events on the stream the phase runs on (ms).  The two maps are
+     * gathered side by side on two streams: ms_gather_global and ms_gather_caustic overlap, ms_gather spans both. */
     float ms_primary, ms_secondary, ms_shadow, ms_gather_global, ms_gather_caustic, ms_resolve, ms_total;
-    float pad;
+    float ms_gather;
+    /* the group kernel of each map's gather (one launch each) and the shade points it answered; the per-query kernel
+     * answers the rest */
+    float ms_group_global, ms_group_caustic;
+    uint32_t grouped_global, grouped_caustic;
 } pm_stats;
 
 /* scheduler::startWorkers(int), src/JobSystem.cpp:76-86 (called at src/Main.cpp:34): `device` takes the place of `cores`. */

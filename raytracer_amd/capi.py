@@ -39,10 +39,11 @@ class Stats(C.Structure):
                 ("absorb_points", C.c_uint64), ("complex_pixels", C.c_uint64),
                 ("ms_primary", C.c_float), ("ms_secondary", C.c_float), ("ms_shadow", C.c_float),
                 ("ms_gather_global", C.c_float), ("ms_gather_caustic", C.c_float), ("ms_resolve", C.c_float),
-                ("ms_total", C.c_float), ("pad", C.c_float)]
+                ("ms_total", C.c_float), ("ms_gather", C.c_float), ("ms_group_global", C.c_float), ("ms_group_caustic", C.c_float),
+                ("grouped_global", C.c_uint32), ("grouped_caustic", C.c_uint32)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "pad"}
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 class PMError(RuntimeError):

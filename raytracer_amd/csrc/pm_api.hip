@@ -55,6 +55,7 @@ struct pm_ctx {
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;           // the caustic gather runs beside the global one
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_g[2][3] = {};          // per map: gather begins, group kernel done, per-query kernel done
     // scene
     int nprims = 0, stride = 0;
     bool lds = true;
@@ -104,6 +105,7 @@ extern "C" int pm_ctx_create(int device, pm_ctx **out) {
     HIPCHK(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    for (int k = 0; k < 2; k++) for (int i = 0; i < 3; i++) HIPCHK(hipEventCreate(&ctx->ev_g[k][i]));
     *out = ctx;
     return PM_OK;
 }
@@ -122,6 +124,7 @@ extern "C" int pm_ctx_destroy(pm_ctx *ctx) {
     if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    for (int k = 0; k < 2; k++) for (int i = 0; i < 3; i++) if (ctx->ev_g[k][i]) (void)hipEventDestroy(ctx->ev_g[k][i]);
     delete ctx;
     return PM_OK;
 }
@@ -574,6 +577,8 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
     }
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
     int n_gathers = 0;
+    bool gathered[2] = {false, false};
+    uint32_t n_primary_sp = 0;
     if (n_sp) {
         LAUNCH_SCENE(k_shadow, dim3((n_sp + 255) / 256), block, ctx, fp, q, n_sp);
         HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
@@ -588,6 +593,7 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
         uint32_t *sched = ctx->sched.as<uint32_t>();
         uint32_t *left = ctx->left.as<uint32_t>();
         const bool use_tiles = ctx->use_tiles && n_sp0 > 0;
+        n_primary_sp = use_tiles ? n_sp0 : 0u;
         const int dbg = getenv("PM_DEBUG") ? 1 : 0;
         // without the group kernel every shade point is in the per-query kernel's range: it simply starts at 0
         const uint32_t sec_lo = use_tiles ? n_sp0 : 0u, sec_n = n_sp - sec_lo;
@@ -601,13 +607,18 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
             hipStream_t st = kind == 0 ? ctx->stream : ctx->aux;
             uint32_t *lk = left + (size_t)kind * n_sp0, *nl = &d_ctr->n_left[kind];
             float4 *strips = ctx->strips.as<float4>() + (size_t)kind * ctx->tile_blocks * TS_STRIDE;
+            HIPCHK(hipEventRecord(ctx->ev_g[kind][0], st));
             if (kind == 0) {
                 if (use_tiles) hipLaunchKernelGGL(k_gather_tile<0>, dim3(ctx->tile_blocks), dim3(64), 0, st, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sched, strips, dbg);
+                HIPCHK(hipEventRecord(ctx->ev_g[kind][1], st));
                 hipLaunchKernelGGL(k_gather<0>, dim3(ctx->query_blocks), block, 0, st, map->view, q, lk, nl, sec_lo, sec_n, sched + SCHED_WORDS);
             } else {
                 if (use_tiles) hipLaunchKernelGGL(k_gather_tile<1>, dim3(ctx->tile_blocks), dim3(64), 0, st, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sched + 2 * SCHED_WORDS, strips, dbg);
+                HIPCHK(hipEventRecord(ctx->ev_g[kind][1], st));
                 hipLaunchKernelGGL(k_gather<1>, dim3(ctx->query_blocks), block, 0, st, map->view, q, lk, nl, sec_lo, sec_n, sched + 3 * SCHED_WORDS);
             }
+            HIPCHK(hipEventRecord(ctx->ev_g[kind][2], st));
+            gathered[kind] = true;
             n_gathers++;
         }
         HIPCHK(hipEventRecord(ctx->ev[4], ctx->stream));            // the global gather is done
@@ -627,6 +638,7 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
             HIPCHK(hipMemcpyAsync(pane + y0 * W, d_pane + y0 * W, (y1 - y0) * W * 4, hipMemcpyDeviceToHost, ctx->stream));
         }
     }
+    if (stats) HIPCHK(hipMemcpyAsync(ctx->h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (getenv("PM_DEBUG")) {
         Counters hc;
@@ -656,8 +668,17 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
         (void)hipEventElapsedTime(&stats->ms_primary, ctx->ev[0], ctx->ev[1]);
         (void)hipEventElapsedTime(&stats->ms_secondary, ctx->ev[1], ctx->ev[2]);
         (void)hipEventElapsedTime(&stats->ms_shadow, ctx->ev[2], ctx->ev[3]);
-        (void)hipEventElapsedTime(&stats->ms_gather_global, ctx->ev[3], ctx->ev[4]);
-        (void)hipEventElapsedTime(&stats->ms_gather_caustic, ctx->ev[4], ctx->ev[5]);
+        (void)hipEventElapsedTime(&stats->ms_gather, ctx->ev[3], ctx->ev[5]);
+        if (gathered[0]) {
+            (void)hipEventElapsedTime(&stats->ms_gather_global, ctx->ev_g[0][0], ctx->ev_g[0][2]);
+            (void)hipEventElapsedTime(&stats->ms_group_global, ctx->ev_g[0][0], ctx->ev_g[0][1]);
+            stats->grouped_global = n_primary_sp ? n_primary_sp - ctx->h_ctr->n_left[0] : 0u;
+        }
+        if (gathered[1]) {
+            (void)hipEventElapsedTime(&stats->ms_gather_caustic, ctx->ev_g[1][0], ctx->ev_g[1][2]);
+            (void)hipEventElapsedTime(&stats->ms_group_caustic, ctx->ev_g[1][0], ctx->ev_g[1][1]);
+            stats->grouped_caustic = n_primary_sp ? n_primary_sp - ctx->h_ctr->n_left[1] : 0u;
+        }
         (void)hipEventElapsedTime(&stats->ms_resolve, ctx->ev[5], ctx->ev[6]);
         (void)hipEventElapsedTime(&stats->ms_total, ctx->ev[0], ctx->ev[6]);
     }
