@@ -73,15 +73,17 @@ struct pm_ctx {
     DevBuf emit_tmp, emit_flag, emit_counts, emit_offs, emit_out;
     DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, bounds;
     hipEvent_t ev[N_EVENTS] = {};
+    std::vector<struct pm_map *> spare;   // destroyed maps whose device buffers wait for the next map (a frame rebuilds both maps)
 };
 
 struct pm_map {
     pm_ctx *ctx = nullptr;
     long long n = 0;
-    DevBuf records, pos4, rest, boxes, cells, keys, cbox;
+    DevBuf records, pos4, rest, cells, keys, cbox, grid;
     MapView view{};
 };
 
+static void free_map(pm_map *map);
 static int set_device(pm_ctx *ctx) { HIPCHK(hipSetDevice(ctx->device)); return PM_OK; }
 
 extern "C" const char *pm_last_error(void) { return g_err.c_str(); }
@@ -118,6 +120,8 @@ extern "C" int pm_ctx_destroy(pm_ctx *ctx) {
                       &ctx->color, &ctx->clist, &ctx->tab, &ctx->ctr, &ctx->pane, &ctx->sched, &ctx->groups, &ctx->left, &ctx->strips, &ctx->emit_tmp, &ctx->emit_flag, &ctx->emit_counts,
                       &ctx->emit_offs, &ctx->emit_out, &ctx->keys_in, &ctx->keys_out, &ctx->vals_in, &ctx->vals_out, &ctx->sort_tmp, &ctx->bounds};
     for (DevBuf *b : bufs) b->release();
+    for (pm_map *m : ctx->spare) free_map(m);
+    ctx->spare.clear();
     if (ctx->h_ctr) (void)hipHostFree(ctx->h_ctr);
     if (ctx->h_u64) (void)hipHostFree(ctx->h_u64);
     for (int i = 0; i < N_EVENTS; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -183,9 +187,10 @@ extern "C" int pm_scene_upload(pm_ctx *ctx, const pm_prim *prims, int32_t n) {
 // ------------------------------------------------------------------------------------- emission
 // attempts [a0, a0+count) -> first `cap` successes, in attempt order, into d_out; *total = successes in range,
 // *last = offset (in the range) of the attempt that produced record cap-1 (or count-1 if fewer successes)
+// total == NULL: do not wait; the count lands in ctx->h_u64[0] when the stream gets there
 static int emit_range(pm_ctx *ctx, int kind, uint64_t seed, const double lc[3], uint64_t a0, uint64_t count, pm_photon *d_out,
                       uint64_t cap, uint64_t *total) {
-    if (count == 0) { *total = 0; return PM_OK; }
+    if (count == 0) { if (total) *total = 0; else ctx->h_u64[0] = 0; return PM_OK; }
     if (count > (1ULL << 31)) return fail(PM_EINVAL, "emit_range: at most 2^31 attempts per call");
     uint32_t nb = (uint32_t)((count + 255) / 256);
     PMCHK(ctx->emit_tmp.ensure(count * sizeof(pm_photon)));
@@ -201,6 +206,7 @@ static int emit_range(pm_ctx *ctx, int kind, uint64_t seed, const double lc[3], 
                        ctx->emit_offs.as<uint64_t>(), count, d_out, cap);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(ctx->h_u64, ctx->emit_offs.as<uint64_t>() + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (!total) return PM_OK;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     *total = ctx->h_u64[0];
     return PM_OK;
@@ -259,41 +265,25 @@ static int build_index(pm_map *map) {
     for (int l = lmax - 1; l >= 0; l--)
         hipLaunchKernelGGL(k_cell_boxes_up, dim3((unsigned)(((1LL << (3 * l)) + 255) / 256)), dim3(256), 0, ctx->stream, map->cells.as<uint32_t>(), l,
                            map->cbox.as<uint64_t>());
-    uint32_t hb[6];
-    HIPCHK(hipMemcpyAsync(hb, ctx->bounds.p, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    auto ord2f_host = [](uint32_t u) { uint32_t b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; memcpy(&f, &b, 4); return f; };
-    float gext = 0.f;
-    for (int a = 0; a < 3; a++) { v.glo[a] = ord2f_host(hb[a]); gext = std::max(gext, ord2f_host(hb[3 + a]) - v.glo[a]); }
-    v.gext = gext; v.gu = (double)gext / 2097152.0; v.lmax = lmax; v.cells = map->cells.as<uint32_t>(); v.keys = map->keys.as<uint64_t>(); v.cbox = map->cbox.as<uint64_t>();
-    // level sizes
-    int cnt[MAX_LEVELS];
-    int top = 0;
-    cnt[0] = (int)((n + 63) / 64);
-    while (cnt[top] > 64) {
-        if (top + 1 >= MAX_LEVELS) return fail(PM_EINVAL, "pm_map_build: too many photons for the tree depth");
-        cnt[top + 1] = (cnt[top] + 63) / 64;
-        top++;
-    }
-    size_t total = 0;
-    for (int t = 0; t <= top; t++) total += (size_t)cnt[t];
-    PMCHK(map->boxes.ensure(total * sizeof(BoxRec)));
-    BoxRec *base = map->boxes.as<BoxRec>();
-    size_t off = 0;
-    for (int t = 0; t <= top; t++) { v.lv[t] = base + off; v.cnt[t] = cnt[t]; off += (size_t)cnt[t]; }
-    v.top = top; v.pos4 = map->pos4.as<float4>(); v.rest = map->rest.as<uint4>();
-    hipLaunchKernelGGL(k_leaf_boxes, dim3((cnt[0] + 3) / 4), dim3(256), 0, ctx->stream, v.pos4, n, const_cast<BoxRec *>(v.lv[0]), cnt[0]);
-    for (int t = 1; t <= top; t++)
-        hipLaunchKernelGGL(k_level_boxes, dim3((cnt[t] + 3) / 4), dim3(256), 0, ctx->stream, v.lv[t - 1], cnt[t - 1], const_cast<BoxRec *>(v.lv[t]), cnt[t]);
+    PMCHK(map->grid.ensure(sizeof(GridParams)));
+    hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(64), 0, ctx->stream, ctx->bounds.as<uint32_t>(), map->grid.as<GridParams>());
+    v.grid = map->grid.as<GridParams>();   // (glo / gext / gu stay zero on the host: kernels load them from here)
+    v.lmax = lmax; v.cells = map->cells.as<uint32_t>(); v.keys = map->keys.as<uint64_t>(); v.cbox = map->cbox.as<uint64_t>();
+    v.pos4 = map->pos4.as<float4>(); v.rest = map->rest.as<uint4>();
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return PM_OK;
+    return PM_OK;   // nothing here waits for the device: the caller synchronises once
+}
+
+// a map object: a recycled one (device buffers of a destroyed map of this context) when there is one
+static pm_map *new_map(pm_ctx *ctx) {
+    if (!ctx->spare.empty()) { pm_map *m = ctx->spare.back(); ctx->spare.pop_back(); return m; }
+    return new (std::nothrow) pm_map();
 }
 
 extern "C" int pm_map_build(pm_ctx *ctx, const pm_photon *records, int64_t n, int32_t records_on_device, pm_map **out) {
     if (!ctx || !out || n < 0 || (n > 0 && !records)) return fail(PM_EINVAL, "pm_map_build: bad argument");
     PMCHK(set_device(ctx));
-    pm_map *map = new (std::nothrow) pm_map();
+    pm_map *map = new_map(ctx);
     if (!map) return fail(PM_ENOMEM, "out of host memory");
     map->ctx = ctx; map->n = n;
     int rc = map->records.ensure((size_t)std::max<int64_t>(n, 1) * sizeof(pm_photon));
@@ -303,6 +293,7 @@ extern "C" int pm_map_build(pm_ctx *ctx, const pm_photon *records, int64_t n, in
         if (e != hipSuccess) rc = fail(PM_EHIP, std::string("copy of photon records failed: ") + hipGetErrorString(e));
     }
     if (rc == PM_OK) rc = build_index(map);
+    if (rc == PM_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(PM_EHIP, "pm_map_build: the build failed on the device");
     if (rc != PM_OK) { pm_map_destroy(map); return rc; }
     *out = map;
     return PM_OK;
@@ -314,27 +305,41 @@ extern "C" int pm_map_create(pm_ctx *ctx, int32_t map_kind, int64_t n, uint64_t 
     if (map_kind != PM_MAP_GLOBAL && map_kind != PM_MAP_CAUSTIC) return fail(PM_EINVAL, "pm_map_create: bad map_kind");
     if (ctx->nprims == 0) return fail(PM_ESTATE, "pm_map_create: no scene uploaded");
     PMCHK(set_device(ctx));
-    pm_map *map = new (std::nothrow) pm_map();
+    pm_map *map = new_map(ctx);
     if (!map) return fail(PM_ENOMEM, "out of host memory");
     map->ctx = ctx; map->n = n;
     int rc = map->records.ensure((size_t)std::max<int64_t>(n, 1) * sizeof(pm_photon));
+    // Consecutive attempt ranges; the result (first n successes in attempt order) does not depend on how they are cut.
+    // The first range is sized to hold n successes with room to spare, and the index is built right behind it without
+    // waiting for the count: one wait per map when the guess holds (it does for any scene close to the reference's).
+    const double yield = map_kind == PM_MAP_GLOBAL ? 0.60 : 0.36;
     uint64_t have = 0, next_attempt = 0;
-    // batches of consecutive attempt ranges; the result (first n successes in attempt order) does not depend on the batch size
-    double yield = map_kind == PM_MAP_GLOBAL ? 0.60 : 0.36;
-    int empty_batches = 0;
-    while (rc == PM_OK && have < (uint64_t)n) {
-        uint64_t want = (uint64_t)n - have;
-        uint64_t batch = std::min<uint64_t>((uint64_t)((double)want / yield) + 4096, 1ULL << 24);
-        uint64_t got = 0;
-        rc = emit_range(ctx, map_kind, seed, light_color, next_attempt, batch, map->records.as<pm_photon>() + have, want, &got);
-        if (rc != PM_OK) break;
-        next_attempt += batch;
-        have += std::min<uint64_t>(got, want);
-        if (got == 0 && ++empty_batches > 8) rc = fail(PM_ESTATE, "pm_map_create: no emission attempt stores a photon in this scene");
+    if (rc == PM_OK && n > 0) {
+        uint64_t batch = std::min<uint64_t>((uint64_t)((double)n / yield) + 4096, 1ULL << 24);
+        rc = emit_range(ctx, map_kind, seed, light_color, 0, batch, map->records.as<pm_photon>(), (uint64_t)n, nullptr);
+        if (rc == PM_OK) rc = build_index(map);
+        if (rc == PM_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(PM_EHIP, "pm_map_create: emission or build failed on the device");
+        if (rc == PM_OK) { next_attempt = batch; have = std::min<uint64_t>(ctx->h_u64[0], (uint64_t)n); }
     }
-    if (rc == PM_OK) rc = build_index(map);
+    if (rc == PM_OK && have < (uint64_t)n) {
+        // the guess did not hold: keep emitting, then build again
+        int empty_batches = 0;
+        while (rc == PM_OK && have < (uint64_t)n) {
+            uint64_t want = (uint64_t)n - have;
+            uint64_t batch = std::min<uint64_t>((uint64_t)((double)want / yield) + 4096, 1ULL << 24);
+            uint64_t got = 0;
+            rc = emit_range(ctx, map_kind, seed, light_color, next_attempt, batch, map->records.as<pm_photon>() + have, want, &got);
+            if (rc != PM_OK) break;
+            next_attempt += batch;
+            have += std::min<uint64_t>(got, want);
+            if (got == 0 && ++empty_batches > 8) rc = fail(PM_ESTATE, "pm_map_create: no emission attempt stores a photon in this scene");
+        }
+        if (rc == PM_OK) rc = build_index(map);
+        if (rc == PM_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(PM_EHIP, "pm_map_create: the build failed on the device");
+    }
+    if (rc == PM_OK && n == 0) rc = build_index(map);
     if (rc != PM_OK) { pm_map_destroy(map); return rc; }
-    if (attempts_used) *attempts_used = next_attempt;   // upper bound: attempts issued (whole batches)
+    if (attempts_used) *attempts_used = next_attempt;   // upper bound: attempts issued (whole ranges)
     *out = map;
     return PM_OK;
 }
@@ -353,11 +358,17 @@ extern "C" int pm_map_download(pm_map *map, pm_photon *host_out) {
     }
     return PM_OK;
 }
+static void free_map(pm_map *map) {
+    map->records.release(); map->pos4.release(); map->rest.release(); map->cells.release(); map->keys.release(); map->cbox.release(); map->grid.release();
+    delete map;
+}
 extern "C" int pm_map_destroy(pm_map *map) {
     if (!map) return PM_OK;
-    if (map->ctx) { (void)hipSetDevice(map->ctx->device); (void)hipStreamSynchronize(map->ctx->stream); }
-    map->records.release(); map->pos4.release(); map->rest.release(); map->boxes.release(); map->cells.release(); map->keys.release(); map->cbox.release();
-    delete map;
+    pm_ctx *ctx = map->ctx;
+    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    // keep the buffers of up to four maps for the next ones (a frame rebuilds both maps; hipFree / hipMalloc of 100 MB cost more than the build)
+    if (ctx && ctx->spare.size() < 4) { map->n = 0; memset(&map->view, 0, sizeof(map->view)); ctx->spare.push_back(map); }
+    else free_map(map);
     return PM_OK;
 }
 

@@ -3,7 +3,7 @@
 #pragma once
 #include "pm_device.h"
 #include "pm_knn.h"
-#include "pm_hilbert.h"
+#include "pm_morton.h"
 #include "pm_grid.h"
 #include "../../include/raytracer_amd.h"
 
@@ -174,12 +174,17 @@ __global__ __launch_bounds__(256) void k_morton(const pm_photon *ph, long long n
     for (int a = 0; a < 3; a++) ext = fmaxf(ext, ord2f(bounds[3 + a]) - ord2f(bounds[a]));
     uint32_t qv[3];
     for (int a = 0; a < 3; a++) qv[a] = quant21(p[a], ord2f(bounds[a]), ext);
-#if PM_USE_GRID
     keys[i] = morton63(qv[0], qv[1], qv[2]);     // linear octree: aligned cells are contiguous key ranges
-#else
-    keys[i] = hilbert3<21>(qv[0], qv[1], qv[2]); // BVH over runs of 64: Hilbert runs are spatially connected
-#endif
     vals[i] = (uint32_t)i;
+}
+
+// the quantisation grid of a map, from the bounds: what the queries need (pm_knn.h, MapView)
+__global__ void k_grid_params(const uint32_t *bounds, GridParams *g) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float ext = 0.f;
+    for (int a = 0; a < 3; a++) { g->glo[a] = ord2f(bounds[a]); ext = fmaxf(ext, ord2f(bounds[3 + a]) - ord2f(bounds[a])); }
+    g->gext = ext;
+    g->gu = (double)ext / 2097152.0;
 }
 
 // cell start tables of the linear octree: entry c of level l = first sorted photon whose key prefix is >= c
@@ -260,38 +265,6 @@ __global__ __launch_bounds__(256) void k_permute(const pm_photon *ph, const uint
     uint4 a = rec[0], b = rec[1];   // a = x y z power ; b = dx dy dz bounce
     pos4[i] = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(o));
     rest[i] = make_uint4(b.x, b.y, b.z, a.w);
-}
-
-__device__ inline float wave_min_f(float v) { for (int s = 1; s < 64; s <<= 1) v = fminf(v, __shfl_xor(v, s)); return v; }
-__device__ inline float wave_max_f(float v) { for (int s = 1; s < 64; s <<= 1) v = fmaxf(v, __shfl_xor(v, s)); return v; }
-
-// one wave per leaf: box of photons [64*leaf, 64*leaf+64)
-__global__ __launch_bounds__(256) void k_leaf_boxes(const float4 *pos4, long long n, BoxRec *boxes, int nleaves) {
-    int leaf = (int)((blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6);
-    int lane = threadIdx.x & 63;
-    if (leaf >= nleaves) return;
-    long long i = (long long)leaf * 64 + lane;
-    const float INF = __int_as_float(0x7F800000);
-    float4 p = i < n ? pos4[i] : make_float4(INF, INF, INF, 0.f);
-    float4 pm = i < n ? p : make_float4(-INF, -INF, -INF, 0.f);
-    BoxRec b;
-    b.lox = wave_min_f(p.x); b.loy = wave_min_f(p.y); b.loz = wave_min_f(p.z); b.pad0 = 0.f;
-    b.hix = wave_max_f(pm.x); b.hiy = wave_max_f(pm.y); b.hiz = wave_max_f(pm.z); b.pad1 = 0.f;
-    if (lane == 0) boxes[leaf] = b;
-}
-// one wave per parent: union of child boxes [64*node, 64*node+64)
-__global__ __launch_bounds__(256) void k_level_boxes(const BoxRec *child, int nchild, BoxRec *parent, int nparent) {
-    int node = (int)((blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6);
-    int lane = threadIdx.x & 63;
-    if (node >= nparent) return;
-    long long i = (long long)node * 64 + lane;
-    const float INF = __int_as_float(0x7F800000);
-    BoxRec c = {INF, INF, INF, 0.f, -INF, -INF, -INF, 0.f};
-    if (i < nchild) c = child[i];
-    BoxRec b;
-    b.lox = wave_min_f(c.lox); b.loy = wave_min_f(c.loy); b.loz = wave_min_f(c.loz); b.pad0 = 0.f;
-    b.hix = wave_max_f(c.hix); b.hiy = wave_max_f(c.hiy); b.hiz = wave_max_f(c.hiz); b.pad1 = 0.f;
-    if (lane == 0) parent[node] = b;
 }
 
 }  // namespace pm

@@ -13,7 +13,7 @@
 // surface (a handful of cells), or far from every photon (only the cells its ball reaches).
 #pragma once
 #include "pm_knn.h"
-#include "pm_hilbert.h"
+#include "pm_morton.h"
 
 namespace pm {
 

@@ -313,8 +313,10 @@ struct WorkDraw {
 // One wave per shade point (pm_grid.h).  Items are the shade points the group kernel left: `left[0 .. *n_left)`, then the
 // slots [sec_lo, sec_lo + sec_n) of the bounced pixels' shade points, which come in no spatial order at all.
 template <int KIND>
-__global__ __launch_bounds__(256) void k_gather(MapView m, SPQueue q, const uint32_t *left, const uint32_t *n_left, uint32_t sec_lo, uint32_t sec_n,
+__global__ __launch_bounds__(256) void k_gather(MapView m_in, SPQueue q, const uint32_t *left, const uint32_t *n_left, uint32_t sec_lo, uint32_t sec_n,
                                                 uint32_t *sched) {
+    MapView m = m_in;
+    load_grid(m);
     __shared__ KnnBuf bufs[4];
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform, and the compiler should know
     KnnBuf *buf = &bufs[wave_in_block];
@@ -355,8 +357,10 @@ __global__ __launch_bounds__(256) void k_gather(MapView m, SPQueue q, const uint
 // One wave per GROUP of shade points (pm_tile.h): the shade points of one 8x8 pixel tile, one per lane.  A group that
 // cannot be gathered as a group appends its slots to `left` for k_gather.
 template <int KIND>
-__global__ __launch_bounds__(64) void k_gather_tile(MapView m, SPQueue q, const uint2 *groups, const Counters *ctr, uint32_t *left, uint32_t *n_left,
+__global__ __launch_bounds__(64) void k_gather_tile(MapView m_in, SPQueue q, const uint2 *groups, const Counters *ctr, uint32_t *left, uint32_t *n_left,
                                                     uint32_t *sched, float4 *strips, int dbg) {
+    MapView m = m_in;
+    load_grid(m);
     __shared__ TileBuf tb;
     const int lane = threadIdx.x;
     const Strip S(reinterpret_cast<float *>(strips + (size_t)blockIdx.x * TS_STRIDE));   // this wave's strip for the shared candidate set
@@ -425,7 +429,9 @@ __global__ __launch_bounds__(64) void k_gather_tile(MapView m, SPQueue q, const 
 
 // standalone gather on caller-provided points (pm_knn_gather): points/normals/radiance are [m][3]
 template <int KIND>
-__global__ __launch_bounds__(256) void k_gather_points(MapView m, const double *pts, const double *nrms, double *rad, long long count) {
+__global__ __launch_bounds__(256) void k_gather_points(MapView m_in, const double *pts, const double *nrms, double *rad, long long count) {
+    MapView m = m_in;
+    load_grid(m);
     __shared__ KnnBuf bufs[4];
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     KnnBuf *buf = &bufs[wave_in_block];
@@ -445,7 +451,9 @@ __global__ __launch_bounds__(256) void k_gather_points(MapView m, const double *
 }
 
 // raw k-NN (pm_knn_query): idx = emission index, ascending (d2, idx)
-__global__ __launch_bounds__(256) void k_knn_query(MapView m, const double *pts, long long count, int32_t *idx, double *d2, int32_t *found, uint32_t *work) {
+__global__ __launch_bounds__(256) void k_knn_query(MapView m_in, const double *pts, long long count, int32_t *idx, double *d2, int32_t *found, uint32_t *work) {
+    MapView m = m_in;
+    load_grid(m);
     __shared__ KnnBuf bufs[4];
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     KnnBuf *buf = &bufs[wave_in_block];
@@ -458,11 +466,7 @@ __global__ __launch_bounds__(256) void k_knn_query(MapView m, const double *pts,
 #ifdef PM_STAMPS
         unsigned long long tq0 = __builtin_amdgcn_s_memtime();
 #endif
-#if PM_USE_GRID
         int f = grid_query(st, buf, m, p, r, MAX_R2);
-#else
-        int f = knn_query(st, buf, m, p, r);
-#endif
 #ifdef PM_STAMPS
         // diagnostic build: the four work words carry cycles (total, node sections, leaf sections, reduces) instead
         unsigned long long tq1 = __builtin_amdgcn_s_memtime();

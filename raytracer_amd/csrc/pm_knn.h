@@ -1,16 +1,16 @@
-// pm_knn.h -- wave-per-query exact k-NN (k = 63) over a 64-ary BVH of Hilbert-sorted photons.
+// pm_knn.h -- shared pieces of the k-NN radiance gather (k = 63): the per-wave candidate buffer, the exact
+// 63rd-smallest select, the per-photon radiance term, and the one-wave-per-query gather.
 //
-// Replaces find_nearest_photons + insert (reference src/PhotonMap.cpp:142-255) and the radiance
-// loops that consume their result (src/Raytrace.cpp:97-131, 136-170).
+// Replaces find_nearest_photons + insert (reference src/PhotonMap.cpp:142-255) and the radiance loops that
+// consume their result (src/Raytrace.cpp:97-131, 136-170).  The search itself is in pm_grid.h (one wave per
+// query, linear octree) and pm_tile.h (one lane per query, groups of neighbouring queries).
 //
-// The reference keeps a 63-entry max-heap per query.  Here one 64-lane wavefront serves one query:
-//   * every tree node has up to 64 children, so ONE coalesced wave load fetches all child boxes of a
-//     node, or all 64 photons of a leaf (one photon per lane);
+// The reference keeps a 63-entry max-heap per query.  Here:
 //   * photons closer than the current bound `lim` are appended, ballot-compacted, to a per-wave LDS
 //     candidate buffer (no ordering is maintained);
 //   * when the buffer holds >= 63 entries for the first time, and whenever it fills up, the exact
-//     63rd-smallest squared distance is found with a wave-wide binary radix select on the IEEE bit
-//     patterns (mostly scalar-unit work: ballots + popcounts), `lim` drops to it and the buffer is
+//     63rd-smallest squared distance is found with a histogram + wave-wide binary radix select on the IEEE
+//     bit patterns (mostly scalar-unit work: ballots + popcounts), `lim` drops to it and the buffer is
 //     compacted to the 63 survivors;
 //   * the radiance sum is order independent: each term is truncated to a multiple of 2^-56 and summed
 //     as 64-bit integers (the canonical sum defined in DESIGN.md), so no sort is needed.
@@ -21,32 +21,16 @@
 namespace pm {
 
 constexpr int KNN_K = 63;
-constexpr int MAX_LEVELS = 5;        // 64^5 photons
 constexpr double MAX_R2 = 100.0;     // MAX_PHOTON_RADIUS, reference src/Raytrace.cpp:13 (compared with squared distance)
 #ifndef PM_KBUF
 #define PM_KBUF 256
 #endif
 constexpr int KBUF = PM_KBUF;        // candidate buffer entries per wave
-#ifndef PM_REDUCE_AT
-#define PM_REDUCE_AT 128             // reduce the buffer to 63 entries when it reaches this (<= KBUF - 64)
-#endif
-#ifndef PM_NEAREST_ALWAYS
-#define PM_NEAREST_ALWAYS 1
-#endif
-#ifndef PM_FIRST_REDUCE_AT
-#define PM_FIRST_REDUCE_AT 128
-#endif
-static_assert(PM_REDUCE_AT <= KBUF - 64 && PM_REDUCE_AT > 63, "a leaf appends up to 64 entries");
-
-struct BoxRec { float lox, loy, loz, pad0, hix, hiy, hiz, pad1; };  // 32 B
 
 struct MapView {
     long long n;                 // photons
     const float4 *pos4;          // sorted order: x, y, z, bits(emission index)
     const uint4 *rest;           // sorted order: bits(dx), bits(dy), bits(dz), power[0..3]
-    int top;                     // index of the top level (its nodes are the root's children)
-    const BoxRec *lv[MAX_LEVELS];// lv[0] = leaf boxes (64 photons each), lv[t] = boxes of 64 lv[t-1] nodes
-    int cnt[MAX_LEVELS];
     // linear octree (pm_grid.h): per-level cell start tables over the key-sorted photons
     const uint64_t *keys;        // sorted 63-bit Morton keys (levels below lmax are resolved by binary search)
     const uint32_t *cells;       // level l occupies [cell_off(l), cell_off(l) + 8^l] (8^l + 1 entries)
@@ -54,7 +38,14 @@ struct MapView {
     int lmax;                    // finest level
     float glo[3], gext;          // cubic quantisation grid: fine index = (p - glo) / gext * 2^21
     double gu;                   // size of a fine unit: gext / 2^21
+    const struct GridParams *grid;  // the same five numbers in device memory, written by the build; kernels copy them in on entry
 };
+struct GridParams { float glo[3], gext; double gu; };
+// a kernel's by-value MapView arrives without the grid numbers (the host never reads them back): fetch them (scalar loads)
+__device__ inline void load_grid(MapView &m) {
+    if (m.n <= 0) return;
+    m.glo[0] = m.grid->glo[0]; m.glo[1] = m.grid->glo[1]; m.glo[2] = m.grid->glo[2]; m.gext = m.grid->gext; m.gu = m.grid->gu;
+}
 __host__ __device__ inline long long cell_off(int l) { return (((1LL << (3 * l)) - 1) / 7) + l; }
 __host__ __device__ inline long long box_off(int l) { return ((1LL << (3 * l)) - 1) / 7; }
 
@@ -105,7 +96,7 @@ __device__ inline unsigned long long readlane_u64(unsigned long long v, int l) {
 struct KnnState {
     double lim;          // wave-uniform: only photons with d2 < lim are collected (starts at MAX_R2)
     int count;           // entries in the buffer
-    bool reduced;        // lim is an exact 63rd-smallest (set by a reduce, cleared when a box bound lowers lim)
+    bool reduced;        // lim is an exact 63rd-smallest (set by a reduce, cleared when a cell bound lowers lim)
     bool any_reduce;     // some reduce has happened: lim is tight from here on
     int lane;
     KnnBuf *buf;
@@ -263,129 +254,6 @@ __device__ inline void knn_reduce(KnnState &st) {
     PM_T1(t_red)
 }
 
-// offer the (up to) 64 photons of one leaf
-__device__ inline void knn_leaf(KnnState &st, const MapView &m, const V3 &q, int leaf) {
-    PM_T0
-    long long i = (long long)leaf * 64 + st.lane;
-    bool valid = i < m.n;
-    st.c_leaves++;
-    float4 p = valid ? m.pos4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    // find_nearest_photons, src/PhotonMap.cpp:211-214
-    double dx = (double)p.x - q.x, dy = (double)p.y - q.y, dz = (double)p.z - q.z;
-    double d2 = dx * dx + dy * dy + dz * dz;
-    bool pass = valid && d2 < st.lim;
-    unsigned long long mask = __ballot(pass);
-    if (mask == 0ULL) { PM_T1(t_leaf) return; }
-    if (pass) {
-        int pos = st.count + lane_rank(mask);
-        st.buf->d[pos] = (unsigned long long)__double_as_longlong(d2);
-        st.buf->i[pos] = (uint32_t)i;
-    }
-    int np = __popcll(mask);
-    st.count += np;
-    st.c_cands += np;
-    PM_T1(t_leaf)
-    // the first reduce comes early (after the nearest leaves) so that lim gets tight; later ones only when the buffer fills
-    if (st.count >= (st.any_reduce ? PM_REDUCE_AT : PM_FIRST_REDUCE_AT)) knn_reduce(st);
-}
-
-// squared distance from q to a box, rounded so that it never exceeds the d2 of a photon inside it
-__device__ inline double box_d2(const BoxRec &b, const V3 &q) {
-    double gx = q.x < (double)b.lox ? (double)b.lox - q.x : (q.x > (double)b.hix ? (double)b.hix - q.x : 0.0);
-    double gy = q.y < (double)b.loy ? (double)b.loy - q.y : (q.y > (double)b.hiy ? (double)b.hiy - q.y : 0.0);
-    double gz = q.z < (double)b.loz ? (double)b.loz - q.z : (q.z > (double)b.hiz ? (double)b.hiz - q.z : 0.0);
-    return gx * gx + gy * gy + gz * gz;
-}
-
-// largest squared distance from q to a point of the box: never below the d2 of a photon inside it
-__device__ inline double box_dmax2(const BoxRec &b, const V3 &q) {
-    double fx = fmax(fabs((double)b.lox - q.x), fabs((double)b.hix - q.x));
-    double fy = fmax(fabs((double)b.loy - q.y), fabs((double)b.hiy - q.y));
-    double fz = fmax(fabs((double)b.loz - q.z), fabs((double)b.hiz - q.z));
-    return fx * fx + fy * fy + fz * fz;
-}
-
-// visit the children of `node` at level LV+1 (they live in m.lv[LV]).  A child that is full (>= 63
-// photons below it) bounds the k-th distance by its farthest corner, so `lim` tightens before any
-// photon is read; the child with the smallest such bound goes first, the rest in lane order.
-template <int LV>
-__device__ inline void knn_visit(KnnState &st, const MapView &m, const V3 &q, int node) {
-    const float INF = __int_as_float(0x7F800000);
-    PM_T0
-    long long c0 = (long long)node * 64;
-    long long ci = c0 + st.lane;
-    st.c_nodes++;
-    double dm = __longlong_as_double(0x7FF0000000000000LL);
-    float fmax2 = INF;
-    if (ci < (long long)m.cnt[LV]) {
-        const float4 *bp = reinterpret_cast<const float4 *>(&m.lv[LV][ci]);
-        float4 lo = bp[0], hi = bp[1];
-        BoxRec b = {lo.x, lo.y, lo.z, 0.f, hi.x, hi.y, hi.z, 0.f};
-        dm = box_d2(b, q);
-        // every node but the last of its level is full (64^(LV+1) >= 63 photons)
-        if (ci + 1 < (long long)m.cnt[LV]) fmax2 = __double2float_ru(box_dmax2(b, q));
-    }
-    float best_max = wave_min_f32(fmax2);
-    int first_c = -1;
-    if (best_max < INF) {
-        // >= 63 photons lie within best_max: collect d2 <= best_max (one double ulp above, since the test is '<')
-        double bound = __longlong_as_double(__double_as_longlong((double)best_max) + 1);
-        if (bound < st.lim) { st.lim = bound; st.reduced = false; }   // lim is a bound again, not an exact k-th distance
-        first_c = __ffsll((long long)__ballot(fmax2 == best_max)) - 1;
-    }
-    bool todo = true;
-    PM_T1(t_node)
-    for (;;) {
-        bool alive = todo && dm < st.lim;
-        unsigned long long mask = __ballot(alive);
-        if (mask == 0ULL) break;
-        int c = __ffsll((long long)mask) - 1;
-        if (first_c >= 0) { if ((mask >> first_c) & 1ULL) c = first_c; first_c = -1; }
-        else if (PM_NEAREST_ALWAYS || !st.any_reduce) {   // nearest child first
-            float key = alive ? (float)dm : INF;
-            float mn = wave_min_f32(key);
-            c = __ffsll((long long)__ballot(alive && key == mn)) - 1;
-        }
-        if (st.lane == c) todo = false;
-        if constexpr (LV == 0) knn_leaf(st, m, q, (int)(c0 + c));
-        else knn_visit<LV - 1>(st, m, q, (int)(c0 + c));
-    }
-}
-
-// Full query.  On return the buffer holds `found` = min(#photons with d2 < 100, 63) entries in lanes'
-// slots 0..found-1 (unordered) and r is the largest of their d2 (the reference's distances[0]).
-__device__ inline int knn_query(KnnState &st, KnnBuf *buf, const MapView &m, const V3 &q, double &r) {
-    st.lane = threadIdx.x & 63;
-    st.buf = buf;
-    st.lim = MAX_R2;
-    st.count = 0;
-    st.reduced = false;
-    st.any_reduce = false;
-    st.c_nodes = st.c_leaves = st.c_reduces = st.c_cands = 0;
-#ifdef PM_STAMPS
-    st.t_node = st.t_leaf = st.t_red = 0;
-#endif
-    r = 0.0;
-    if (m.n <= 0) return 0;
-    switch (m.top) {
-    case 0: knn_visit<0>(st, m, q, 0); break;
-    case 1: knn_visit<1>(st, m, q, 0); break;
-    case 2: knn_visit<2>(st, m, q, 0); break;
-    case 3: knn_visit<3>(st, m, q, 0); break;
-    default: knn_visit<4>(st, m, q, 0); break;
-    }
-    if (st.count > KNN_K) knn_reduce(st);
-    if (st.count == 0) return 0;
-    if (st.reduced) { r = st.lim; return st.count; }   // count == 63 and the largest entry is lim itself
-    // fewer than 63 photons within the radius: r = max of what was found (rare: tiny maps)
-    wave_lds_fence();
-    double d = st.lane < st.count ? __longlong_as_double((long long)st.buf->d[st.lane]) : 0.0;
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) d = fmax(d, __shfl_xor(d, s));
-    r = d;
-    return st.count;
-}
-
 // One photon's term of the radiance sums: src/Raytrace.cpp:100-125 (global), :139-164 (caustic)
 template <int KIND>
 __device__ inline void photon_term(const float4 &pp, const uint4 &rr, const V3 &p, const V3 &nrm, double pd2, double r,
@@ -416,15 +284,7 @@ __device__ inline void photon_term(const float4 &pp, const uint4 &rr, const V3 &
     }
 }
 
-#ifndef PM_USE_GRID
-#define PM_USE_GRID 1
-#endif
 __device__ inline int grid_query(KnnState &st, KnnBuf *buf, const MapView &m, const V3 &q, double &r, double lim0);   // pm_grid.h
-#if PM_USE_GRID
-#define KNN_QUERY(st, buf, m, p, r, lim0) grid_query(st, buf, m, p, r, lim0)
-#else
-#define KNN_QUERY(st, buf, m, p, r, lim0) knn_query(st, buf, m, p, r)
-#endif
 
 constexpr double FX_SCALE = 72057594037927936.0;   // 2^56
 
@@ -442,7 +302,7 @@ template <int KIND>
 __device__ inline void knn_gather(KnnBuf *buf, const MapView &m, const V3 &p, const V3 &nrm, double &R, double &G, double &B, KnnCarry &carry) {
     KnnState st;
     double r;
-    int found = KNN_QUERY(st, buf, m, p, r, carry_bound(carry, p));
+    int found = grid_query(st, buf, m, p, r, carry_bound(carry, p));
     carry.at = p; carry.r = r; carry.full = found == KNN_K;
     R = G = B = 0.0;
     if (found == 0) return;
