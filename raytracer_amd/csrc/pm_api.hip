@@ -260,7 +260,7 @@ static int build_index(pm_map *map) {
     hipLaunchKernelGGL(k_cell_tables, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, ctx->stream, ctx->keys_out.as<uint64_t>(), n,
                        map->cells.as<uint32_t>(), lmax);
     PMCHK(map->cbox.ensure((size_t)box_off(lmax + 1) * 8));
-    hipLaunchKernelGGL(k_cell_boxes_fine, dim3((unsigned)(((1LL << (3 * lmax)) * 64 + 255) / 256)), dim3(256), 0, ctx->stream, map->pos4.as<float4>(),
+    hipLaunchKernelGGL(k_cell_boxes_fine, dim3((unsigned)(((1LL << (3 * lmax)) + 255) / 256)), dim3(256), 0, ctx->stream, map->pos4.as<float4>(),
                        map->cells.as<uint32_t>(), lmax, ctx->bounds.as<uint32_t>(), map->cbox.as<uint64_t>());
     for (int l = lmax - 1; l >= 0; l--)
         hipLaunchKernelGGL(k_cell_boxes_up, dim3((unsigned)(((1LL << (3 * l)) + 255) / 256)), dim3(256), 0, ctx->stream, map->cells.as<uint32_t>(), l,

@@ -211,29 +211,43 @@ __device__ inline uint64_t pack_box(const uint32_t lo[3], const uint32_t hi[3]) 
     for (int a = 0; a < 3; a++) w |= ((uint64_t)lo[a] << (20 * a)) | ((uint64_t)hi[a] << (20 * a + 10));
     return w;
 }
-// finest table level: one wave per cell, lanes stride over its photons (a caustic focus puts 10^5 photons in one cell)
+// finest table level: one lane per cell (most cells hold a handful of photons or none); a cell with more than 32
+// photons is then reduced by the whole wave
 __global__ __launch_bounds__(256) void k_cell_boxes_fine(const float4 *pos4, const uint32_t *cells, int lmax, const uint32_t *bounds, uint64_t *cbox) {
-    long long c = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    int lane = threadIdx.x & 63;
-    if (c >= (1LL << (3 * lmax))) return;
+    const long long ncell = 1LL << (3 * lmax);
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const uint32_t *tab = cells + cell_off(lmax);
-    uint32_t first = tab[c], end = tab[c + 1];
-    if (first == end) return;
+    uint32_t first = 0, end = 0;
+    if (c < ncell) { first = tab[c]; end = tab[c + 1]; }
     float glo[3] = {ord2f(bounds[0]), ord2f(bounds[1]), ord2f(bounds[2])}, ext = 0.f;
     for (int a = 0; a < 3; a++) ext = fmaxf(ext, ord2f(bounds[3 + a]) - glo[a]);
     const int sh = 21 - lmax;   // >= 13
-    uint32_t lo[3] = {1023u, 1023u, 1023u}, hi[3] = {0u, 0u, 0u};
-    for (uint32_t i = first + (uint32_t)lane; i < end; i += 64u) {
-        float4 p = pos4[i];
+    auto slice = [&](const float4 &p, uint32_t lo[3], uint32_t hi[3]) {
         float pa[3] = {p.x, p.y, p.z};
         for (int a = 0; a < 3; a++) {
             uint32_t sub = (quant21(pa[a], glo[a], ext) & ((1u << sh) - 1u)) >> (sh - 10);
             lo[a] = min(lo[a], sub); hi[a] = max(hi[a], sub);
         }
+    };
+    // a cell holding thousands of photons is a dense blob that queries split further anyway: its box is the whole cube
+    const bool huge = end - first > 4096u;
+    if (huge) { const uint32_t lo[3] = {0u, 0u, 0u}, hi[3] = {1023u, 1023u, 1023u}; cbox[box_off(lmax) + c] = pack_box(lo, hi); }
+    const bool big = !huge && end - first > 32u;
+    if (end > first && !big && !huge) {
+        uint32_t lo[3] = {1023u, 1023u, 1023u}, hi[3] = {0u, 0u, 0u};
+        for (uint32_t i = first; i < end; i++) slice(pos4[i], lo, hi);
+        cbox[box_off(lmax) + c] = pack_box(lo, hi);
     }
-    for (int a = 0; a < 3; a++)
-        for (int s = 1; s < 64; s <<= 1) { lo[a] = min(lo[a], (uint32_t)__shfl_xor((int)lo[a], s)); hi[a] = max(hi[a], (uint32_t)__shfl_xor((int)hi[a], s)); }
-    if (lane == 0) cbox[box_off(lmax) + c] = pack_box(lo, hi);
+    for (unsigned long long todo = __ballot(big); todo; todo &= todo - 1) {
+        const int src = __ffsll((long long)todo) - 1;
+        const uint32_t f = (uint32_t)__shfl((int)first, src), e = (uint32_t)__shfl((int)end, src);
+        uint32_t lo[3] = {1023u, 1023u, 1023u}, hi[3] = {0u, 0u, 0u};
+        for (uint32_t i = f + (uint32_t)lane; i < e; i += 64u) slice(pos4[i], lo, hi);
+        for (int a = 0; a < 3; a++)
+            for (int s = 1; s < 64; s <<= 1) { lo[a] = min(lo[a], (uint32_t)__shfl_xor((int)lo[a], s)); hi[a] = max(hi[a], (uint32_t)__shfl_xor((int)hi[a], s)); }
+        if (lane == src) cbox[box_off(lmax) + c] = pack_box(lo, hi);
+    }
 }
 // level l from level l + 1: union of the non-empty children, halved into the parent's 1/1024 slices
 __global__ __launch_bounds__(256) void k_cell_boxes_up(const uint32_t *cells, int l, uint64_t *cbox) {

@@ -23,6 +23,7 @@ __device__ inline uint32_t quant21(float p, float lo, float ext) {   // shared b
 }
 __device__ inline uint64_t morton63(uint32_t x, uint32_t y, uint32_t z) { return spread21(x) | (spread21(y) << 1) | (spread21(z) << 2); }
 
+constexpr int GRID_MAX_LEVEL = 16;   // cells are not split below this level: photons are sorted on the top 48 key bits only (pm_sort.hip)
 #ifndef PM_GRID_SPLIT
 #define PM_GRID_SPLIT 128      // a queued cell holding more photons than this is split into its 8 children before it is read
 #endif
@@ -209,7 +210,7 @@ __device__ inline int grid_query(KnnState &st, KnnBuf *buf, const MapView &m, co
         if (!alive) cnt = 0;
         const unsigned long long am = __ballot(alive);
         if (am == 0ULL) break;
-        const bool big = alive && cnt > (uint32_t)PM_GRID_SPLIT && lev < 21;
+        const bool big = alive && cnt > (uint32_t)PM_GRID_SPLIT && lev < GRID_MAX_LEVEL;
         const unsigned long long bm = __ballot(big);
         const float fkey = (float)dmin2;      // order of the walk only; pruning uses dmin2 itself
         const float fb = bm ? wave_min_f32(big ? fkey : INF) : INF;

@@ -89,7 +89,7 @@ __device__ inline int tile_collect(TileBuf *tb, const Strip &S, const MapView &m
         if (!alive) cnt = 0;
         const unsigned long long am = __ballot(alive);
         if (am == 0ULL) break;
-        const bool big = alive && cnt > (uint32_t)PM_GRID_SPLIT && lev < 21;
+        const bool big = alive && cnt > (uint32_t)PM_GRID_SPLIT && lev < GRID_MAX_LEVEL;
         unsigned long long todo = __ballot(big);
         unsigned long long freem = ~am;
         if (todo && __popcll(freem) + 1 >= 8) {
