@@ -54,6 +54,8 @@ struct pm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;           // the caustic gather runs beside the global one
+    hipStream_t aux2 = nullptr;          // and the per-query gather of the bounced pixels' shade points beside both
+    hipEvent_t ev_join2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_g[2][3] = {};          // per map: gather begins, group kernel done, per-query kernel done
     // scene
@@ -105,6 +107,8 @@ extern "C" int pm_ctx_create(int device, pm_ctx **out) {
     HIPCHK(hipHostMalloc((void **)&ctx->h_u64, 4 * sizeof(uint64_t), hipHostMallocDefault));
     for (int i = 0; i < N_EVENTS; i++) HIPCHK(hipEventCreate(&ctx->ev[i]));
     HIPCHK(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&ctx->aux2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     for (int k = 0; k < 2; k++) for (int i = 0; i < 3; i++) HIPCHK(hipEventCreate(&ctx->ev_g[k][i]));
@@ -126,6 +130,8 @@ extern "C" int pm_ctx_destroy(pm_ctx *ctx) {
     if (ctx->h_u64) (void)hipHostFree(ctx->h_u64);
     for (int i = 0; i < N_EVENTS; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
+    if (ctx->aux2) { (void)hipStreamSynchronize(ctx->aux2); (void)hipStreamDestroy(ctx->aux2); }
+    if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     for (int k = 0; k < 2; k++) for (int i = 0; i < 3; i++) if (ctx->ev_g[k][i]) (void)hipEventDestroy(ctx->ev_g[k][i]);
@@ -597,10 +603,10 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
         // the group kernel left and for the shade points of bounced pixels (k_gather).  Both kernels are launched with
         // as many blocks as the device keeps resident and draw their work from device counters.
         PMCHK(gather_blocks(ctx));
-        PMCHK(ctx->sched.ensure(4 * SCHED_WORDS * 4 + 2 * 8192 * 16));
+        PMCHK(ctx->sched.ensure(6 * SCHED_WORDS * 4 + 2 * 8192 * 16));
         PMCHK(ctx->left.ensure((size_t)2 * n_sp0 * 4 + 8));
         PMCHK(ctx->strips.ensure((size_t)2 * ctx->tile_blocks * TS_STRIDE * sizeof(float4)));
-        HIPCHK(hipMemsetAsync(ctx->sched.p, 0, 4 * SCHED_WORDS * 4, ctx->stream));   // 64 work counters per gather launch
+        HIPCHK(hipMemsetAsync(ctx->sched.p, 0, 6 * SCHED_WORDS * 4, ctx->stream));   // 64 work counters per gather launch
         uint32_t *sched = ctx->sched.as<uint32_t>();
         uint32_t *left = ctx->left.as<uint32_t>();
         const bool use_tiles = ctx->use_tiles && n_sp0 > 0;
@@ -608,10 +614,14 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
         const int dbg = getenv("PM_DEBUG") ? 1 : 0;
         // without the group kernel every shade point is in the per-query kernel's range: it simply starts at 0
         const uint32_t sec_lo = use_tiles ? n_sp0 : 0u, sec_n = n_sp - sec_lo;
-        // The two maps are gathered side by side: the global map on the caller's stream, the caustic map on the context's
-        // second stream, so that the thin end of one launch (few groups left, most CUs idle) is filled by the other.
+        // Three streams side by side, so that the thin end of one launch (few items left, most CUs idle) is filled by the
+        // others: the global map's groups on the caller's stream, the caustic map's groups on a second, and on a third the
+        // per-query gather of the bounced pixels' shade points (no spatial order: never grouped) for both maps.  Each group
+        // kernel is followed, on its stream, by the per-query kernel for what it left.
         HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
         HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+        HIPCHK(hipStreamWaitEvent(ctx->aux2, ctx->ev_fork, 0));
+        const uint32_t *zero = &d_ctr->pad[0];   // "nothing left": the third stream's launches have only the bounced range
         for (int kind = 0; kind < 2; kind++) {
             pm_map *map = kind == 0 ? gmap : cmap;
             if (rp->flags & (kind == 0 ? PM_FLAG_NO_GLOBAL : PM_FLAG_NO_CAUSTIC)) continue;
@@ -620,18 +630,26 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
             float4 *strips = ctx->strips.as<float4>() + (size_t)kind * ctx->tile_blocks * TS_STRIDE;
             HIPCHK(hipEventRecord(ctx->ev_g[kind][0], st));
             if (kind == 0) {
-                if (use_tiles) hipLaunchKernelGGL(k_gather_tile<0>, dim3(ctx->tile_blocks), dim3(64), 0, st, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sched, strips, dbg);
+                if (use_tiles) {
+                    hipLaunchKernelGGL(k_gather<0>, dim3(ctx->query_blocks), block, 0, ctx->aux2, map->view, q, lk, zero, sec_lo, sec_n, sched + 4 * SCHED_WORDS);
+                    hipLaunchKernelGGL(k_gather_tile<0>, dim3(ctx->tile_blocks), dim3(64), 0, st, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sched, strips, dbg);
+                }
                 HIPCHK(hipEventRecord(ctx->ev_g[kind][1], st));
-                hipLaunchKernelGGL(k_gather<0>, dim3(ctx->query_blocks), block, 0, st, map->view, q, lk, nl, sec_lo, sec_n, sched + SCHED_WORDS);
+                hipLaunchKernelGGL(k_gather<0>, dim3(ctx->query_blocks), block, 0, st, map->view, q, lk, nl, sec_lo, use_tiles ? 0u : sec_n, sched + SCHED_WORDS);
             } else {
-                if (use_tiles) hipLaunchKernelGGL(k_gather_tile<1>, dim3(ctx->tile_blocks), dim3(64), 0, st, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sched + 2 * SCHED_WORDS, strips, dbg);
+                if (use_tiles) {
+                    hipLaunchKernelGGL(k_gather<1>, dim3(ctx->query_blocks), block, 0, ctx->aux2, map->view, q, lk, zero, sec_lo, sec_n, sched + 5 * SCHED_WORDS);
+                    hipLaunchKernelGGL(k_gather_tile<1>, dim3(ctx->tile_blocks), dim3(64), 0, st, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sched + 2 * SCHED_WORDS, strips, dbg);
+                }
                 HIPCHK(hipEventRecord(ctx->ev_g[kind][1], st));
-                hipLaunchKernelGGL(k_gather<1>, dim3(ctx->query_blocks), block, 0, st, map->view, q, lk, nl, sec_lo, sec_n, sched + 3 * SCHED_WORDS);
+                hipLaunchKernelGGL(k_gather<1>, dim3(ctx->query_blocks), block, 0, st, map->view, q, lk, nl, sec_lo, use_tiles ? 0u : sec_n, sched + 3 * SCHED_WORDS);
             }
             HIPCHK(hipEventRecord(ctx->ev_g[kind][2], st));
             gathered[kind] = true;
             n_gathers++;
         }
+        HIPCHK(hipEventRecord(ctx->ev_join2, ctx->aux2));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join2, 0));
         HIPCHK(hipEventRecord(ctx->ev[4], ctx->stream));            // the global gather is done
         HIPCHK(hipEventRecord(ctx->ev_join, ctx->aux));
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
@@ -658,13 +676,18 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
                     hc.n_groups, hc.n_left[0], hc.n_left[1]);
         fprintf(stderr, "[pm] lanes handed over, by reason (few photons, spread, radius, |S|, no lane served, -, own shortfall): %u %u %u %u %u %u %u\n", hc.why[1], hc.why[2],
                 hc.why[3], hc.why[4], hc.why[5], hc.why[6], hc.why[7]);
+        for (int k = 0; k < 2; k++) {
+            fprintf(stderr, "[pm] groups of map %d by log2(ticks):", k);
+            for (int b = 10; b < 32; b++) fprintf(stderr, " %d:%u", b, hc.ghist[k][b]);
+            fprintf(stderr, "\n");
+        }
         fprintf(stderr, "[pm] group kernel ticks per phase (centre query, collect, pass 1, pass 2, rank, sum): %llu %llu %llu %llu %llu %llu; shared sets %llu, candidates %llu\n", hc.tphase[0],
                 hc.tphase[1], hc.tphase[2], hc.tphase[3], hc.tphase[4], hc.tphase[5], hc.tphase[7], hc.tphase[6]);
     }
 #ifdef PM_WAVE_TIMES
     if (const char *path = getenv("PM_WAVE_DUMP")) {
         std::vector<uint32_t> h(2 * 8192 * 4);
-        if (n_sp && hipMemcpy(h.data(), ctx->sched.as<uint32_t>() + 4 * SCHED_WORDS, h.size() * 4, hipMemcpyDeviceToHost) == hipSuccess)
+        if (n_sp && hipMemcpy(h.data(), ctx->sched.as<uint32_t>() + 6 * SCHED_WORDS, h.size() * 4, hipMemcpyDeviceToHost) == hipSuccess)
             if (FILE *f = fopen(path, "wb")) { fwrite(h.data(), 4, h.size(), f); fclose(f); }
     }
 #endif

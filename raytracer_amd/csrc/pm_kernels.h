@@ -26,7 +26,7 @@ struct FrameParams {
     int rank, world;
 };
 
-struct Counters { uint32_t n_sp, n_complex, n_secondary, n_groups, n_left[2], pad[2]; uint32_t why[8]; unsigned long long tphase[8]; };   // n_left[k]: shade points left to the per-query gather of map k
+struct Counters { uint32_t n_sp, n_complex, n_secondary, n_groups, n_left[2], pad[2]; uint32_t why[8]; unsigned long long tphase[8]; uint32_t ghist[2][32]; };   // n_left[k]: shade points left to the per-query gather of map k
 
 // shade point queue (SoA)
 struct SPQueue {
@@ -369,52 +369,28 @@ __global__ __launch_bounds__(64) void k_gather_tile(MapView m_in, SPQueue q, con
     WorkDraw wd;
     uint32_t i0, i1;
     while (wd.next(sched, n_groups, 1u, i0, i1)) {
+#ifdef PM_TILE_STAMPS
+        const unsigned long long tg0 = __builtin_amdgcn_s_memtime();
+#endif
         const uint2 g = groups[i0];
         const bool active = (uint32_t)lane < g.y;
         const uint32_t s = g.x + (active ? (uint32_t)lane : 0u);
         const V3 p = {q.geo[0 * (size_t)q.cap + s], q.geo[1 * (size_t)q.cap + s], q.geo[2 * (size_t)q.cap + s]};
         const V3 nrm = {q.geo[3 * (size_t)q.cap + s], q.geo[4 * (size_t)q.cap + s], q.geo[5 * (size_t)q.cap + s]};
-        // The whole group first; a part too spread out for one shared set is cut in two across the longest side of its
-        // bounding box (three times at most) and the pieces are served one after the other.  todo: not answered yet;
-        // dead: goes to the per-query kernel; pid / pdepth: the piece a lane belongs to and how often it was cut.
-        bool todo = active, dead = false;
-        int pid = 0, pdepth = 0, npieces = 1;
-        double r_scale = 0.0;
+        // dead: the lane goes to the per-query kernel (its group is too spread out for one shared set, or the lane itself
+        // came up short)
+        double R, G, B, r_scale = 0.0;
         int why = 0;
-        for (int round = 0; round < 16; round++) {
-            const unsigned long long tmask = __ballot(todo);
-            if (tmask == 0ULL) break;
-            const int cur = __builtin_amdgcn_readlane(pid, __ffsll((long long)tmask) - 1);   // any piece that is still open
-            const bool part = todo && pid == cur;
-            const unsigned long long pmask = __ballot(part);
-            // idle lanes repeat the piece's first point: the bounding box is that of the piece
-            const int f = __ffsll((long long)pmask) - 1;
-            const V3 pf = {__shfl(p.x, f), __shfl(p.y, f), __shfl(p.z, f)};   // (every lane must take part in the exchange)
-            const V3 pe = part ? p : pf;
-            double R, G, B;
-            const bool ok = tile_gather<KIND>(&tb, S, m, pe, nrm, part, r_scale, R, G, B, why, const_cast<unsigned long long *>(ctr->tphase));
-            if ((why == 2 || why == 4) && __builtin_amdgcn_readlane(pdepth, f) < 3 && __popcll(pmask) > 1) {
-                const V3 lo = {wave_min_f64(pe.x), wave_min_f64(pe.y), wave_min_f64(pe.z)}, hi = {wave_max_f64(pe.x), wave_max_f64(pe.y), wave_max_f64(pe.z)};
-                const double ex = hi.x - lo.x, ey = hi.y - lo.y, ez = hi.z - lo.z;
-                const bool low = ex >= ey && ex >= ez ? p.x <= 0.5 * (lo.x + hi.x) : (ey >= ez ? p.y <= 0.5 * (lo.y + hi.y) : p.z <= 0.5 * (lo.z + hi.z));
-                if (part) { pdepth++; if (!low) pid = npieces; }
-                npieces++;
-                continue;
-            }
-            if (why != 0) { if (part) dead = true; }        // nothing was computed for this piece
-            else if (part) {
-                if (ok) { out[0 * (size_t)q.cap + s] = R; out[1 * (size_t)q.cap + s] = G; out[2 * (size_t)q.cap + s] = B; }
-                else dead = true;
-            }
-            if (dbg) {   // diagnostic: lanes handed over, by reason (7 = the lane's own shortfall)
-                const int lost = __popcll(__ballot(part && (why != 0 || !ok)));
-                if (lane == 0 && lost) atomicAdd(const_cast<uint32_t *>(&ctr->why[why != 0 ? (why & 7) : 7]), (uint32_t)lost);
-            }
-            if (part) todo = false;
+        const bool ok = tile_gather<KIND>(&tb, S, m, p, nrm, active, r_scale, R, G, B, why, const_cast<unsigned long long *>(ctr->tphase));
+        if (ok) { out[0 * (size_t)q.cap + s] = R; out[1 * (size_t)q.cap + s] = G; out[2 * (size_t)q.cap + s] = B; }
+        bool dead = active && !ok;
+        const bool todo = false;
+        if (dbg) {   // diagnostic: lanes handed over, by reason (7 = the lane's own shortfall)
+            const int lost = __popcll(__ballot(dead));
+            if (lane == 0 && lost) atomicAdd(const_cast<uint32_t *>(&ctr->why[why != 0 ? (why & 7) : 7]), (uint32_t)lost);
         }
-#ifdef PM_TILE_PRINT
-        { int nt = __popcll(__ballot(todo)), nd = __popcll(__ballot(dead));
-          if (lane == 0 && (i0 % 61) == 0 && KIND == 0) printf("group %u n %u pieces %d still-open %d dead %d last why %d\n", i0, g.y, npieces, nt, nd, why); }
+#ifdef PM_TILE_STAMPS
+        if (lane == 0) { unsigned long long dt = __builtin_amdgcn_s_memtime() - tg0; atomicAdd(const_cast<uint32_t *>(&ctr->ghist[KIND][63 - __clzll((long long)(dt | 1ULL))]), 1u); }
 #endif
         if (todo) dead = true;
         const unsigned long long lm = __ballot(dead);

@@ -23,6 +23,10 @@ namespace pm {
 #ifndef PM_TILE_BETA2
 #define PM_TILE_BETA2 1.6     // shared squared radius of a group, in units of the centre query's 63rd squared distance
 #endif
+#ifndef PM_TILE_EST_MAX
+#define PM_TILE_EST_MAX 1200   // expected size of the shared set beyond which a group is left to the per-query kernel: one wave
+                              // would sit on it for many times the average while independent queries spread over the device
+#endif
 #ifndef PM_TS_CAP
 #define PM_TS_CAP 2048
 #endif
@@ -264,7 +268,7 @@ __device__ inline bool tile_gather(TileBuf *tb, const Strip &S, const MapView &m
 #ifdef PM_TILE_PRINT
         if (0) printf("blk %d e %.4f %.4f %.4f rad %.4f r_scale %.6f est %.1f nact %d\n", (int)blockIdx.x, e[0], e[1], e[2], rad, r_scale, area * 63.0 / (3.14159 * r_scale), (int)__popcll(__ballot(active)));
 #endif
-        if (area * (double)KNN_K > 1.25 * (double)TS_CAP * 3.14159 * r_scale) { why = 2; return false; }
+        if (area * (double)KNN_K > (double)PM_TILE_EST_MAX * 3.14159 * r_scale) { why = 2; return false; }
     }
     // 2. the shared candidate set: everything closer than sqrt(L) to the box, so everything closer than that to any lane's
     //    point (collected with a hair more than L: the two distances are rounded differently)
