@@ -31,6 +31,22 @@ ALGO_BYTES_PER_GATHER = 63 * 32      # k photon records of 32 B (SURVEY section 
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes of this same command (tools/profile_bench.sh:
+    FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs; rocprofv3 reports KB; gfx950 correction: FETCH_SIZE tallies the
+    128-byte read requests at 64 bytes, so it is doubled -- MI355X_MICROARCH.md, HBM section)."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_per_dispatch_avg.json")
+    try:
+        with open(path) as f:
+            pmc = json.load(f)
+        for name, c in pmc.items():
+            if kernel in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, "2 x FETCH_SIZE + WRITE_SIZE of profiles/r01/pmc_per_dispatch_avg.json (not collected live)"
+    except (OSError, ValueError):
+        pass
+    return None, "no PMC summary found"
+
+
 def cpu_baseline(frame, args, cores):
     """Oracle ("port") on the host cores: every `stride`-th row of the same frame, same photon maps."""
     import numpy as np
@@ -141,6 +157,7 @@ def main():
         dom_ms = (phase["ms_group_global"], phase["ms_group_caustic"])[k] / args.steps
         dom_units = (st.grouped_global, st.grouped_caustic)[k]
         achieved = ALGO_BYTES_PER_GATHER * dom_units / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic, traffic_note = pmc_traffic(("k_gather_tile<0>", "k_gather_tile<1>")[k])
         out = {
             "metric": "Mrays/sec + photon-gathers/sec at 1440p, 1/2/4/8 GPUs; frame time (s)",
             "value": rays / step_s / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -152,7 +169,7 @@ def main():
             "gathers_per_s": gathers / step_s, "frame_time_s": step_s, "rays_per_frame": rays, "gathers_per_frame": gathers,
             "phases_ms_rank0": {**{k: v / args.steps for k, v in phase.items()}, "maps_emit_and_build_wall": t_maps / args.steps * 1e3},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "note": f"algorithmic bytes = {ALGO_BYTES_PER_GATHER} B x {int(dom_units)} gathers answered per launch; avg launch {dom_ms:.3f} ms "
                                  f"(HIP events on the stream the kernel is launched on; the other map's gather runs beside it on a second stream)"},
         }
