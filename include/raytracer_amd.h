@@ -109,8 +109,8 @@ int pm_emit_range(pm_ctx *ctx, int32_t map_kind, uint64_t seed, const double lig
                   uint64_t attempt_begin, uint64_t attempt_count, pm_photon *d_out, uint64_t cap,
                   uint64_t *out_count);
 
-/* createKDTree (src/PhotonMap.cpp:64-140): builds the spatial index (64-ary BVH over Morton-sorted
- * photons) from n records in emission order.  records_on_device: 0 = host pointer, 1 = device. */
+/* createKDTree (src/PhotonMap.cpp:64-140): builds the spatial index (linear octree over
+ * Morton-sorted photons) from n records in emission order.  records_on_device: 0 = host pointer, 1 = device. */
 int pm_map_build(pm_ctx *ctx, const pm_photon *records, int64_t n, int32_t records_on_device, pm_map **out);
 
 /* createPhotonMap / createCausticPhotonMap (src/PhotonMap.h:28-29): the first n successful attempts,
@@ -130,7 +130,7 @@ int pm_knn_query(pm_ctx *ctx, pm_map *map, int64_t m, const double *points, int3
                  int32_t *found);
 
 /* pm_knn_query plus per-query work counters (diagnostics; no counterpart in the reference):
- * work[4q..4q+3] = tree nodes visited, leaves visited, sort-merges, single insertions. */
+ * work[4q..4q+3] = cell splits, chunks of 64 photons read, buffer reduces, candidates collected. */
 int pm_knn_profile(pm_ctx *ctx, pm_map *map, int64_t m, const double *points, int32_t *idx, double *d2,
                    int32_t *found, uint32_t *work);
 
