@@ -126,8 +126,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ta = time.perf_counter()
-        frame.build_maps()
-        torch.cuda.synchronize()
+        frame.build_maps()      # emission + build are left on the library's build streams; render waits for them where it needs them
         t_maps += time.perf_counter() - ta
         st = frame.render()
         frame.gather_pane()
@@ -167,7 +166,7 @@ def main():
                                    f"k=63, 25 shadow rays, depth<=3 (BASELINE config 2); step = emit both maps + build indices + trace/shade + pane on rank 0",
                        "seed": args.seed, "parallelism": f"rows x{world} (16-row blocks), emission attempts x{world} + all-gather"},
             "gathers_per_s": gathers / step_s, "frame_time_s": step_s, "rays_per_frame": rays, "gathers_per_frame": gathers,
-            "phases_ms_rank0": {**{k: v / args.steps for k, v in phase.items()}, "maps_emit_and_build_wall": t_maps / args.steps * 1e3},
+            "phases_ms_rank0": {**{k: v / args.steps for k, v in phase.items()}, "maps_enqueue_host_wall": t_maps / args.steps * 1e3},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "note": f"algorithmic bytes = {ALGO_BYTES_PER_GATHER} B x {int(dom_units)} gathers answered per launch; avg launch {dom_ms:.3f} ms "

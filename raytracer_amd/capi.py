@@ -191,12 +191,13 @@ class Context:
             _check(self.lib.pm_map_build(self.handle, records.ctypes.data, len(records), 0, C.byref(h)))
         return PhotonMap(self, h, kind)
 
-    def create_map(self, kind, n, seed, light_color=(0.6, 0.6, 0.6)):
-        """createPhotonMap / createCausticPhotonMap (src/PhotonMap.h:28-29)."""
+    def create_map(self, kind, n, seed, light_color=(0.6, 0.6, 0.6), wait=True):
+        """createPhotonMap / createCausticPhotonMap (src/PhotonMap.h:28-29).  wait=False: emission and build are left on
+        one of the library's build streams and the call returns at once; the first use of the map waits for them."""
         h, used = C.c_void_p(), C.c_uint64()
-        _check(self.lib.pm_map_create(self.handle, kind, int(n), int(seed), _vec3(light_color), C.byref(h), C.byref(used)))
+        _check(self.lib.pm_map_create(self.handle, kind, int(n), int(seed), _vec3(light_color), C.byref(h), C.byref(used) if wait else None))
         m = PhotonMap(self, h, kind)
-        m.attempts_issued = used.value
+        m.attempts_issued = used.value if wait else None
         return m
 
     def knn_query(self, pmap, points):

@@ -50,6 +50,15 @@ struct DevBuf {
 constexpr size_t LDS_SCENE_MAX = 48 * 1024;   // scenes up to this size are staged in LDS; larger ones are read from global memory
 constexpr int N_EVENTS = 8;
 
+struct BuildSlot {
+    hipStream_t stream = nullptr;
+    DevBuf emit_tmp, emit_flag, emit_counts, emit_offs, keys_in, keys_out, vals_in, vals_out, sort_tmp, bounds;
+    void release() {
+        DevBuf *b[] = {&emit_tmp, &emit_flag, &emit_counts, &emit_offs, &keys_in, &keys_out, &vals_in, &vals_out, &sort_tmp, &bounds};
+        for (DevBuf *x : b) x->release();
+    }
+};
+
 struct pm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -71,9 +80,12 @@ struct pm_ctx {
     uint32_t sp_cap = 0;
     Counters *h_ctr = nullptr;   // pinned
     uint64_t *h_u64 = nullptr;   // pinned scratch (2 words)
-    // emission / build scratch
-    DevBuf emit_tmp, emit_flag, emit_counts, emit_offs, emit_out;
-    DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, bounds;
+    // emission / build scratch: slots 0 and 1 have streams of their own (pm_map_create / pm_map_build leave the work there
+    // and return; two maps are built side by side, and beside the first passes of the frame that needs them); slot 2 runs
+    // on the caller's stream (pm_emit_range, and whatever has to be redone synchronously)
+    BuildSlot slot[3];
+    int next_slot = 0;
+    hipEvent_t ev_order = nullptr;       // "the caller's stream got here": a build starts behind it
     hipEvent_t ev[N_EVENTS] = {};
     std::vector<struct pm_map *> spare;   // destroyed maps whose device buffers wait for the next map (a frame rebuilds both maps)
 };
@@ -81,6 +93,13 @@ struct pm_ctx {
 struct pm_map {
     pm_ctx *ctx = nullptr;
     long long n = 0;
+    // a map whose emission + build are still on a slot's stream: `ready` marks their end, *h_got (pinned) then holds the
+    // photons the one emission range produced; map_ready() waits, checks, and emits more in the rare case it fell short
+    bool pending = false;
+    int slot = 2;
+    hipEvent_t ready = nullptr;
+    uint64_t *h_got = nullptr;
+    int kind = 0; uint64_t seed = 0, next_attempt = 0; double lc[3] = {0, 0, 0};
     DevBuf records, pos4, rest, cells, keys, cbox, grid;
     MapView view{};
 };
@@ -107,6 +126,8 @@ extern "C" int pm_ctx_create(int device, pm_ctx **out) {
     HIPCHK(hipHostMalloc((void **)&ctx->h_u64, 4 * sizeof(uint64_t), hipHostMallocDefault));
     for (int i = 0; i < N_EVENTS; i++) HIPCHK(hipEventCreate(&ctx->ev[i]));
     HIPCHK(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) HIPCHK(hipStreamCreateWithFlags(&ctx->slot[i].stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
     HIPCHK(hipStreamCreateWithFlags(&ctx->aux2, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
@@ -120,9 +141,11 @@ extern "C" int pm_ctx_destroy(pm_ctx *ctx) {
     if (!ctx) return PM_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 2; i++) if (ctx->slot[i].stream) { (void)hipStreamSynchronize(ctx->slot[i].stream); (void)hipStreamDestroy(ctx->slot[i].stream); }
+    for (int i = 0; i < 3; i++) ctx->slot[i].release();
+    if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
     DevBuf *bufs[] = {&ctx->scene, &ctx->geo, &ctx->obj, &ctx->pixel, &ctx->node, &ctx->tabslot, &ctx->direct, &ctx->radg, &ctx->radc,
-                      &ctx->color, &ctx->clist, &ctx->tab, &ctx->ctr, &ctx->pane, &ctx->sched, &ctx->groups, &ctx->left, &ctx->strips, &ctx->emit_tmp, &ctx->emit_flag, &ctx->emit_counts,
-                      &ctx->emit_offs, &ctx->emit_out, &ctx->keys_in, &ctx->keys_out, &ctx->vals_in, &ctx->vals_out, &ctx->sort_tmp, &ctx->bounds};
+                      &ctx->color, &ctx->clist, &ctx->tab, &ctx->ctr, &ctx->pane, &ctx->sched, &ctx->groups, &ctx->left, &ctx->strips};
     for (DevBuf *b : bufs) b->release();
     for (pm_map *m : ctx->spare) free_map(m);
     ctx->spare.clear();
@@ -184,37 +207,38 @@ extern "C" int pm_scene_upload(pm_ctx *ctx, const pm_prim *prims, int32_t n) {
     return PM_OK;
 }
 
-#define LAUNCH_SCENE(kern, grid, block, ctx, ...)                                                                 \
+#define LAUNCH_SCENE_ON(kern, grid, block, ctx, strm, ...)                                                        \
     do {                                                                                                          \
-        if ((ctx)->lds) hipLaunchKernelGGL(kern<true>, grid, block, (ctx)->scene_b, (ctx)->stream, (ctx)->gv, __VA_ARGS__); \
-        else hipLaunchKernelGGL(kern<false>, grid, block, 0, (ctx)->stream, (ctx)->gv, __VA_ARGS__);              \
+        if ((ctx)->lds) hipLaunchKernelGGL(kern<true>, grid, block, (ctx)->scene_b, strm, (ctx)->gv, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kern<false>, grid, block, 0, strm, (ctx)->gv, __VA_ARGS__);                       \
     } while (0)
+#define LAUNCH_SCENE(kern, grid, block, ctx, ...) LAUNCH_SCENE_ON(kern, grid, block, ctx, (ctx)->stream, __VA_ARGS__)
 
 // ------------------------------------------------------------------------------------- emission
-// attempts [a0, a0+count) -> first `cap` successes, in attempt order, into d_out; *total = successes in range,
-// *last = offset (in the range) of the attempt that produced record cap-1 (or count-1 if fewer successes)
-// total == NULL: do not wait; the count lands in ctx->h_u64[0] when the stream gets there
-static int emit_range(pm_ctx *ctx, int kind, uint64_t seed, const double lc[3], uint64_t a0, uint64_t count, pm_photon *d_out,
-                      uint64_t cap, uint64_t *total) {
-    if (count == 0) { if (total) *total = 0; else ctx->h_u64[0] = 0; return PM_OK; }
+// attempts [a0, a0+count) -> first `cap` successes, in attempt order, into d_out, on the slot's stream with the slot's
+// scratch; the number of successes in the range lands in *h_got (pinned) when the stream gets there.
+// total != NULL: wait for it.
+static int emit_range(pm_ctx *ctx, BuildSlot &sl, int kind, uint64_t seed, const double lc[3], uint64_t a0, uint64_t count, pm_photon *d_out,
+                      uint64_t cap, uint64_t *h_got, uint64_t *total) {
+    if (count == 0) { *h_got = 0; if (total) *total = 0; return PM_OK; }
     if (count > (1ULL << 31)) return fail(PM_EINVAL, "emit_range: at most 2^31 attempts per call");
     uint32_t nb = (uint32_t)((count + 255) / 256);
-    PMCHK(ctx->emit_tmp.ensure(count * sizeof(pm_photon)));
-    PMCHK(ctx->emit_flag.ensure(count));
-    PMCHK(ctx->emit_counts.ensure((size_t)nb * 4));
-    PMCHK(ctx->emit_offs.ensure(((size_t)nb + 1) * 8));
+    PMCHK(sl.emit_tmp.ensure(count * sizeof(pm_photon)));
+    PMCHK(sl.emit_flag.ensure(count));
+    PMCHK(sl.emit_counts.ensure((size_t)nb * 4));
+    PMCHK(sl.emit_offs.ensure(((size_t)nb + 1) * 8));
     uint64_t K = stream_key(seed, kind == PM_MAP_GLOBAL ? KIND_EMIT_GLOBAL : KIND_EMIT_CAUSTIC);
     V3 light = {lc[0], lc[1], lc[2]};
-    LAUNCH_SCENE(k_emit, dim3(nb), dim3(256), ctx, kind, K, light, a0, count, ctx->emit_tmp.as<pm_photon>(), ctx->emit_flag.as<uint8_t>(),
-                 ctx->emit_counts.as<uint32_t>());
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, ctx->emit_counts.as<uint32_t>(), ctx->emit_offs.as<uint64_t>(), nb);
-    hipLaunchKernelGGL(k_emit_scatter, dim3(nb), dim3(256), 0, ctx->stream, ctx->emit_tmp.as<pm_photon>(), ctx->emit_flag.as<uint8_t>(),
-                       ctx->emit_offs.as<uint64_t>(), count, d_out, cap);
+    LAUNCH_SCENE_ON(k_emit, dim3(nb), dim3(256), ctx, sl.stream, kind, K, light, a0, count, sl.emit_tmp.as<pm_photon>(), sl.emit_flag.as<uint8_t>(),
+                    sl.emit_counts.as<uint32_t>());
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, sl.stream, sl.emit_counts.as<uint32_t>(), sl.emit_offs.as<uint64_t>(), nb);
+    hipLaunchKernelGGL(k_emit_scatter, dim3(nb), dim3(256), 0, sl.stream, sl.emit_tmp.as<pm_photon>(), sl.emit_flag.as<uint8_t>(),
+                       sl.emit_offs.as<uint64_t>(), count, d_out, cap);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(ctx->h_u64, ctx->emit_offs.as<uint64_t>() + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(h_got, sl.emit_offs.as<uint64_t>() + nb, 8, hipMemcpyDeviceToHost, sl.stream));
     if (!total) return PM_OK;
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    *total = ctx->h_u64[0];
+    HIPCHK(hipStreamSynchronize(sl.stream));
+    *total = *h_got;
     return PM_OK;
 }
 
@@ -224,12 +248,12 @@ extern "C" int pm_emit_range(pm_ctx *ctx, int32_t map_kind, uint64_t seed, const
     if (map_kind != PM_MAP_GLOBAL && map_kind != PM_MAP_CAUSTIC) return fail(PM_EINVAL, "pm_emit_range: bad map_kind");
     if (ctx->nprims == 0) return fail(PM_ESTATE, "pm_emit_range: no scene uploaded");
     PMCHK(set_device(ctx));
-    return emit_range(ctx, map_kind, seed, light_color, attempt_begin, attempt_count, d_out, cap, out_count);
+    ctx->slot[2].stream = ctx->stream;
+    return emit_range(ctx, ctx->slot[2], map_kind, seed, light_color, attempt_begin, attempt_count, d_out, cap, ctx->h_u64, out_count);
 }
 
 // ---------------------------------------------------------------------------------------- build
-static int build_index(pm_map *map) {
-    pm_ctx *ctx = map->ctx;
+static int build_index(pm_map *map, BuildSlot &sl) {
     long long n = map->n;
     MapView &v = map->view;
     memset(&v, 0, sizeof(v));
@@ -237,24 +261,24 @@ static int build_index(pm_map *map) {
     if (n == 0) return PM_OK;
     if (n > (1LL << 31) - 64) return fail(PM_EINVAL, "pm_map_build: at most 2^31-64 photons per map");
     const pm_photon *rec = map->records.as<pm_photon>();
-    PMCHK(ctx->keys_in.ensure((size_t)n * 8)); PMCHK(ctx->keys_out.ensure((size_t)n * 8));
-    PMCHK(ctx->vals_in.ensure((size_t)n * 4)); PMCHK(ctx->vals_out.ensure((size_t)n * 4));
-    PMCHK(ctx->bounds.ensure(6 * 4));
+    PMCHK(sl.keys_in.ensure((size_t)n * 8)); PMCHK(sl.keys_out.ensure((size_t)n * 8));
+    PMCHK(sl.vals_in.ensure((size_t)n * 4)); PMCHK(sl.vals_out.ensure((size_t)n * 4));
+    PMCHK(sl.bounds.ensure(6 * 4));
     PMCHK(map->pos4.ensure((size_t)n * 16)); PMCHK(map->rest.ensure((size_t)n * 16));
     uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
-    HIPCHK(hipMemcpyAsync(ctx->bounds.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(sl.bounds.p, init, sizeof(init), hipMemcpyHostToDevice, sl.stream));
     unsigned nbk = (unsigned)std::min<long long>((n + 255) / 256, 512);
     unsigned nb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_bounds, dim3(nbk), dim3(256), 0, ctx->stream, rec, n, ctx->bounds.as<uint32_t>());
-    hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, ctx->stream, rec, n, ctx->bounds.as<uint32_t>(), ctx->keys_in.as<uint64_t>(),
-                       ctx->vals_in.as<uint32_t>());
+    hipLaunchKernelGGL(k_bounds, dim3(nbk), dim3(256), 0, sl.stream, rec, n, sl.bounds.as<uint32_t>());
+    hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, sl.stream, rec, n, sl.bounds.as<uint32_t>(), sl.keys_in.as<uint64_t>(),
+                       sl.vals_in.as<uint32_t>());
     size_t tmp_bytes = 0;
-    HIPCHK(sort_pairs_u64(nullptr, tmp_bytes, ctx->keys_in.as<uint64_t>(), ctx->keys_out.as<uint64_t>(), ctx->vals_in.as<uint32_t>(),
-                          ctx->vals_out.as<uint32_t>(), (size_t)n, ctx->stream));
-    PMCHK(ctx->sort_tmp.ensure(tmp_bytes));
-    HIPCHK(sort_pairs_u64(ctx->sort_tmp.p, tmp_bytes, ctx->keys_in.as<uint64_t>(), ctx->keys_out.as<uint64_t>(), ctx->vals_in.as<uint32_t>(),
-                          ctx->vals_out.as<uint32_t>(), (size_t)n, ctx->stream));
-    hipLaunchKernelGGL(k_permute, dim3(nb), dim3(256), 0, ctx->stream, rec, ctx->vals_out.as<uint32_t>(), n, map->pos4.as<float4>(),
+    HIPCHK(sort_pairs_u64(nullptr, tmp_bytes, sl.keys_in.as<uint64_t>(), sl.keys_out.as<uint64_t>(), sl.vals_in.as<uint32_t>(),
+                          sl.vals_out.as<uint32_t>(), (size_t)n, sl.stream));
+    PMCHK(sl.sort_tmp.ensure(tmp_bytes));
+    HIPCHK(sort_pairs_u64(sl.sort_tmp.p, tmp_bytes, sl.keys_in.as<uint64_t>(), sl.keys_out.as<uint64_t>(), sl.vals_in.as<uint32_t>(),
+                          sl.vals_out.as<uint32_t>(), (size_t)n, sl.stream));
+    hipLaunchKernelGGL(k_permute, dim3(nb), dim3(256), 0, sl.stream, rec, sl.vals_out.as<uint32_t>(), n, map->pos4.as<float4>(),
                        map->rest.as<uint4>());
     // linear octree tables
     int lmax = 0;
@@ -262,17 +286,17 @@ static int build_index(pm_map *map) {
     long long ncells = cell_off(lmax + 1);
     PMCHK(map->cells.ensure((size_t)ncells * 4));
     PMCHK(map->keys.ensure((size_t)n * 8));
-    HIPCHK(hipMemcpyAsync(map->keys.p, ctx->keys_out.p, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_cell_tables, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, ctx->stream, ctx->keys_out.as<uint64_t>(), n,
+    HIPCHK(hipMemcpyAsync(map->keys.p, sl.keys_out.p, (size_t)n * 8, hipMemcpyDeviceToDevice, sl.stream));
+    hipLaunchKernelGGL(k_cell_tables, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, sl.stream, sl.keys_out.as<uint64_t>(), n,
                        map->cells.as<uint32_t>(), lmax);
     PMCHK(map->cbox.ensure((size_t)box_off(lmax + 1) * 8));
-    hipLaunchKernelGGL(k_cell_boxes_fine, dim3((unsigned)(((1LL << (3 * lmax)) + 255) / 256)), dim3(256), 0, ctx->stream, map->pos4.as<float4>(),
-                       map->cells.as<uint32_t>(), lmax, ctx->bounds.as<uint32_t>(), map->cbox.as<uint64_t>());
+    hipLaunchKernelGGL(k_cell_boxes_fine, dim3((unsigned)(((1LL << (3 * lmax)) + 255) / 256)), dim3(256), 0, sl.stream, map->pos4.as<float4>(),
+                       map->cells.as<uint32_t>(), lmax, sl.bounds.as<uint32_t>(), map->cbox.as<uint64_t>());
     for (int l = lmax - 1; l >= 0; l--)
-        hipLaunchKernelGGL(k_cell_boxes_up, dim3((unsigned)(((1LL << (3 * l)) + 255) / 256)), dim3(256), 0, ctx->stream, map->cells.as<uint32_t>(), l,
+        hipLaunchKernelGGL(k_cell_boxes_up, dim3((unsigned)(((1LL << (3 * l)) + 255) / 256)), dim3(256), 0, sl.stream, map->cells.as<uint32_t>(), l,
                            map->cbox.as<uint64_t>());
     PMCHK(map->grid.ensure(sizeof(GridParams)));
-    hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(64), 0, ctx->stream, ctx->bounds.as<uint32_t>(), map->grid.as<GridParams>());
+    hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(64), 0, sl.stream, sl.bounds.as<uint32_t>(), map->grid.as<GridParams>());
     v.grid = map->grid.as<GridParams>();   // (glo / gext / gu stay zero on the host: kernels load them from here)
     v.lmax = lmax; v.cells = map->cells.as<uint32_t>(); v.keys = map->keys.as<uint64_t>(); v.cbox = map->cbox.as<uint64_t>();
     v.pos4 = map->pos4.as<float4>(); v.rest = map->rest.as<uint4>();
@@ -282,8 +306,52 @@ static int build_index(pm_map *map) {
 
 // a map object: a recycled one (device buffers of a destroyed map of this context) when there is one
 static pm_map *new_map(pm_ctx *ctx) {
-    if (!ctx->spare.empty()) { pm_map *m = ctx->spare.back(); ctx->spare.pop_back(); return m; }
-    return new (std::nothrow) pm_map();
+    pm_map *m = nullptr;
+    if (!ctx->spare.empty()) { m = ctx->spare.back(); ctx->spare.pop_back(); }
+    else m = new (std::nothrow) pm_map();
+    if (!m) return nullptr;
+    if (!m->ready && hipEventCreateWithFlags(&m->ready, hipEventDisableTiming) != hipSuccess) { delete m; return nullptr; }
+    if (!m->h_got && hipHostMalloc((void **)&m->h_got, sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) { (void)hipEventDestroy(m->ready); delete m; return nullptr; }
+    m->ctx = ctx; m->pending = false;
+    return m;
+}
+// the next build slot (0 / 1 in turn), its stream ordered behind what the caller's stream holds now
+static int take_slot(pm_ctx *ctx, int &slot) {
+    slot = ctx->next_slot;
+    ctx->next_slot ^= 1;
+    HIPCHK(hipEventRecord(ctx->ev_order, ctx->stream));
+    HIPCHK(hipStreamWaitEvent(ctx->slot[slot].stream, ctx->ev_order, 0));
+    return PM_OK;
+}
+
+// Wait for a map whose emission and build were left on a slot's stream and make sure it holds its n photons.
+static int map_ready(pm_map *map) {
+    if (!map || !map->pending) return PM_OK;
+    pm_ctx *ctx = map->ctx;
+    map->pending = false;
+    if (hipEventSynchronize(map->ready) != hipSuccess) return fail(PM_EHIP, "photon map: emission or build failed on the device");
+    if (map->kind < 0) return PM_OK;   // built from records: nothing to check
+    const uint64_t n = (uint64_t)map->n;
+    uint64_t have = std::min<uint64_t>(*map->h_got, n);
+    if (have >= n) return PM_OK;
+    // the one range fell short of n photons (a scene that stores far fewer photons per attempt than the reference's):
+    // keep emitting, synchronously on the caller's stream, then build again
+    const double yield = map->kind == PM_MAP_GLOBAL ? 0.60 : 0.36;
+    BuildSlot &sl = ctx->slot[2];
+    sl.stream = ctx->stream;
+    int empty_batches = 0;
+    while (have < n) {
+        uint64_t want = n - have;
+        uint64_t batch = std::min<uint64_t>((uint64_t)((double)want / yield) + 4096, 1ULL << 24);
+        uint64_t got = 0;
+        PMCHK(emit_range(ctx, sl, map->kind, map->seed, map->lc, map->next_attempt, batch, map->records.as<pm_photon>() + have, want, ctx->h_u64, &got));
+        map->next_attempt += batch;
+        have += std::min<uint64_t>(got, want);
+        if (got == 0 && ++empty_batches > 8) return fail(PM_ESTATE, "pm_map_create: no emission attempt stores a photon in this scene");
+    }
+    PMCHK(build_index(map, sl));
+    HIPCHK(hipStreamSynchronize(sl.stream));
+    return PM_OK;
 }
 
 extern "C" int pm_map_build(pm_ctx *ctx, const pm_photon *records, int64_t n, int32_t records_on_device, pm_map **out) {
@@ -291,16 +359,20 @@ extern "C" int pm_map_build(pm_ctx *ctx, const pm_photon *records, int64_t n, in
     PMCHK(set_device(ctx));
     pm_map *map = new_map(ctx);
     if (!map) return fail(PM_ENOMEM, "out of host memory");
-    map->ctx = ctx; map->n = n;
+    map->n = n; map->kind = -1;
     int rc = map->records.ensure((size_t)std::max<int64_t>(n, 1) * sizeof(pm_photon));
     if (rc == PM_OK && n > 0) {
+        // the copy is ordered on the caller's stream (the caller may reuse `records` behind this call); the build follows
+        // on a slot's stream and is waited for by the first use of the map
         hipError_t e = hipMemcpyAsync(map->records.p, records, (size_t)n * sizeof(pm_photon),
                                       records_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) rc = fail(PM_EHIP, std::string("copy of photon records failed: ") + hipGetErrorString(e));
     }
-    if (rc == PM_OK) rc = build_index(map);
-    if (rc == PM_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(PM_EHIP, "pm_map_build: the build failed on the device");
+    if (rc == PM_OK) rc = take_slot(ctx, map->slot);
+    if (rc == PM_OK) rc = build_index(map, ctx->slot[map->slot]);
+    if (rc == PM_OK && hipEventRecord(map->ready, ctx->slot[map->slot].stream) != hipSuccess) rc = fail(PM_EHIP, "pm_map_build: hipEventRecord failed");
     if (rc != PM_OK) { pm_map_destroy(map); return rc; }
+    map->pending = true;
     *out = map;
     return PM_OK;
 }
@@ -313,39 +385,28 @@ extern "C" int pm_map_create(pm_ctx *ctx, int32_t map_kind, int64_t n, uint64_t 
     PMCHK(set_device(ctx));
     pm_map *map = new_map(ctx);
     if (!map) return fail(PM_ENOMEM, "out of host memory");
-    map->ctx = ctx; map->n = n;
+    map->n = n; map->kind = map_kind; map->seed = seed; map->next_attempt = 0;
+    for (int a = 0; a < 3; a++) map->lc[a] = light_color[a];
     int rc = map->records.ensure((size_t)std::max<int64_t>(n, 1) * sizeof(pm_photon));
     // Consecutive attempt ranges; the result (first n successes in attempt order) does not depend on how they are cut.
-    // The first range is sized to hold n successes with room to spare, and the index is built right behind it without
-    // waiting for the count: one wait per map when the guess holds (it does for any scene close to the reference's).
+    // The first range is sized to hold n successes with room to spare, and the index is built right behind it on a
+    // slot's stream without waiting for the count.  With attempts_used == NULL the call returns at once: the first
+    // use of the map waits (map_ready), so two maps are emitted and built side by side, beside the first passes of the
+    // frame that needs them.  When the guess does not hold (it does for any scene close to the reference's) map_ready
+    // emits more and builds again.
     const double yield = map_kind == PM_MAP_GLOBAL ? 0.60 : 0.36;
-    uint64_t have = 0, next_attempt = 0;
-    if (rc == PM_OK && n > 0) {
-        uint64_t batch = std::min<uint64_t>((uint64_t)((double)n / yield) + 4096, 1ULL << 24);
-        rc = emit_range(ctx, map_kind, seed, light_color, 0, batch, map->records.as<pm_photon>(), (uint64_t)n, nullptr);
-        if (rc == PM_OK) rc = build_index(map);
-        if (rc == PM_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(PM_EHIP, "pm_map_create: emission or build failed on the device");
-        if (rc == PM_OK) { next_attempt = batch; have = std::min<uint64_t>(ctx->h_u64[0], (uint64_t)n); }
+    if (rc == PM_OK) rc = take_slot(ctx, map->slot);
+    if (rc == PM_OK) {
+        BuildSlot &sl = ctx->slot[map->slot];
+        uint64_t batch = n > 0 ? std::min<uint64_t>((uint64_t)((double)n / yield) + 4096, 1ULL << 24) : 0;
+        rc = emit_range(ctx, sl, map_kind, seed, light_color, 0, batch, map->records.as<pm_photon>(), (uint64_t)n, map->h_got, nullptr);
+        map->next_attempt = batch;
+        if (rc == PM_OK) rc = build_index(map, sl);
+        if (rc == PM_OK && hipEventRecord(map->ready, sl.stream) != hipSuccess) rc = fail(PM_EHIP, "pm_map_create: hipEventRecord failed");
     }
-    if (rc == PM_OK && have < (uint64_t)n) {
-        // the guess did not hold: keep emitting, then build again
-        int empty_batches = 0;
-        while (rc == PM_OK && have < (uint64_t)n) {
-            uint64_t want = (uint64_t)n - have;
-            uint64_t batch = std::min<uint64_t>((uint64_t)((double)want / yield) + 4096, 1ULL << 24);
-            uint64_t got = 0;
-            rc = emit_range(ctx, map_kind, seed, light_color, next_attempt, batch, map->records.as<pm_photon>() + have, want, &got);
-            if (rc != PM_OK) break;
-            next_attempt += batch;
-            have += std::min<uint64_t>(got, want);
-            if (got == 0 && ++empty_batches > 8) rc = fail(PM_ESTATE, "pm_map_create: no emission attempt stores a photon in this scene");
-        }
-        if (rc == PM_OK) rc = build_index(map);
-        if (rc == PM_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(PM_EHIP, "pm_map_create: the build failed on the device");
-    }
-    if (rc == PM_OK && n == 0) rc = build_index(map);
+    if (rc == PM_OK) { map->pending = true; if (attempts_used) rc = map_ready(map); }
     if (rc != PM_OK) { pm_map_destroy(map); return rc; }
-    if (attempts_used) *attempts_used = next_attempt;   // upper bound: attempts issued (whole ranges)
+    if (attempts_used) *attempts_used = map->next_attempt;   // upper bound: attempts issued (whole ranges)
     *out = map;
     return PM_OK;
 }
@@ -358,6 +419,7 @@ extern "C" int pm_map_size(const pm_map *map, int64_t *n) {
 extern "C" int pm_map_download(pm_map *map, pm_photon *host_out) {
     if (!map || (!host_out && map->n)) return fail(PM_EINVAL, "pm_map_download: NULL argument");
     PMCHK(set_device(map->ctx));
+    PMCHK(map_ready(map));
     if (map->n) {
         HIPCHK(hipMemcpyAsync(host_out, map->records.p, (size_t)map->n * sizeof(pm_photon), hipMemcpyDeviceToHost, map->ctx->stream));
         HIPCHK(hipStreamSynchronize(map->ctx->stream));
@@ -366,12 +428,18 @@ extern "C" int pm_map_download(pm_map *map, pm_photon *host_out) {
 }
 static void free_map(pm_map *map) {
     map->records.release(); map->pos4.release(); map->rest.release(); map->cells.release(); map->keys.release(); map->cbox.release(); map->grid.release();
+    if (map->ready) (void)hipEventDestroy(map->ready);
+    if (map->h_got) (void)hipHostFree(map->h_got);
     delete map;
 }
 extern "C" int pm_map_destroy(pm_map *map) {
     if (!map) return PM_OK;
     pm_ctx *ctx = map->ctx;
-    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        if (map->pending) { (void)hipEventSynchronize(map->ready); map->pending = false; }   // its build may still be running
+        (void)hipStreamSynchronize(ctx->stream);
+    }
     // keep the buffers of up to four maps for the next ones (a frame rebuilds both maps; hipFree / hipMalloc of 100 MB cost more than the build)
     if (ctx && ctx->spare.size() < 4) { map->n = 0; memset(&map->view, 0, sizeof(map->view)); ctx->spare.push_back(map); }
     else free_map(map);
@@ -390,6 +458,7 @@ static int knn_query_impl(pm_ctx *ctx, pm_map *map, int64_t m, const double *poi
     if (!ctx || !map || m < 0 || (m && (!points || !idx || !d2 || !found))) return fail(PM_EINVAL, "pm_knn_query: bad argument");
     if (m == 0) return PM_OK;
     PMCHK(set_device(ctx));
+    PMCHK(map_ready(map));
     DevBuf dp, di, dd, df, dw;
     int rc = dp.ensure((size_t)m * 24);
     if (rc == PM_OK) rc = di.ensure((size_t)m * KNN_K * 4);
@@ -430,6 +499,7 @@ extern "C" int pm_knn_gather(pm_ctx *ctx, pm_map *map, int32_t map_kind, int64_t
     if (map_kind != PM_MAP_GLOBAL && map_kind != PM_MAP_CAUSTIC) return fail(PM_EINVAL, "pm_knn_gather: bad map_kind");
     if (m == 0) return PM_OK;
     PMCHK(set_device(ctx));
+    PMCHK(map_ready(map));
     DevBuf dp, dn, dr;
     const double *p = points, *nn = normals;
     double *r = radiance;
@@ -625,6 +695,9 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
         for (int kind = 0; kind < 2; kind++) {
             pm_map *map = kind == 0 ? gmap : cmap;
             if (rp->flags & (kind == 0 ? PM_FLAG_NO_GLOBAL : PM_FLAG_NO_CAUSTIC)) continue;
+            // the map may still be under construction on its build stream (beside the passes above, and beside the other
+            // map's gather): wait for it here
+            PMCHK(map_ready(map));
             hipStream_t st = kind == 0 ? ctx->stream : ctx->aux;
             uint32_t *lk = left + (size_t)kind * n_sp0, *nl = &d_ctr->n_left[kind];
             float4 *strips = ctx->strips.as<float4>() + (size_t)kind * ctx->tile_blocks * TS_STRIDE;

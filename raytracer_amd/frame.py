@@ -140,7 +140,7 @@ class GpuFrame:
             if self.flags & (1 << kind):
                 continue
             if self.dist is None:
-                self.maps[kind] = self.ctx.create_map(kind, self.n, self.seed, self.light_color)
+                self.maps[kind] = self.ctx.create_map(kind, self.n, self.seed, self.light_color, wait=False)
             else:
                 chunks, _ = emit_sharded(self.n, kind, self.world, self.rank, self._emit_fn(kind), self._allgather)
                 rec = torch.cat(chunks) if len(chunks) != 1 else chunks[0].contiguous()
