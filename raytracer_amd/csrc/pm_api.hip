@@ -125,10 +125,11 @@ extern "C" int pm_ctx_create(int device, pm_ctx **out) {
     HIPCHK(hipHostMalloc((void **)&ctx->h_ctr, sizeof(Counters), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&ctx->h_u64, 4 * sizeof(uint64_t), hipHostMallocDefault));
     for (int i = 0; i < N_EVENTS; i++) HIPCHK(hipEventCreate(&ctx->ev[i]));
-    HIPCHK(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+    // two streams beside the caller's: more would share hardware queues (4 per process) and serialise behind each other.
+    // They carry the map builds, and later in the frame the caustic gather and the bounced pixels' gathers.
     for (int i = 0; i < 2; i++) HIPCHK(hipStreamCreateWithFlags(&ctx->slot[i].stream, hipStreamNonBlocking));
+    ctx->aux = ctx->slot[0].stream; ctx->aux2 = ctx->slot[1].stream;
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
-    HIPCHK(hipStreamCreateWithFlags(&ctx->aux2, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
@@ -152,8 +153,6 @@ extern "C" int pm_ctx_destroy(pm_ctx *ctx) {
     if (ctx->h_ctr) (void)hipHostFree(ctx->h_ctr);
     if (ctx->h_u64) (void)hipHostFree(ctx->h_u64);
     for (int i = 0; i < N_EVENTS; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
-    if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
-    if (ctx->aux2) { (void)hipStreamSynchronize(ctx->aux2); (void)hipStreamDestroy(ctx->aux2); }
     if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
