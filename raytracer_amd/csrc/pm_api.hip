@@ -691,7 +691,10 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
         HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
         HIPCHK(hipStreamWaitEvent(ctx->aux2, ctx->ev_fork, 0));
         const uint32_t *zero = &d_ctr->pad[0];   // "nothing left": the third stream's launches have only the bounced range
-        for (int kind = 0; kind < 2; kind++) {
+        // the map whose build is already over goes first
+        const bool global_late = gmap && gmap->pending && hipEventQuery(gmap->ready) != hipSuccess;
+        for (int turn = 0; turn < 2; turn++) {
+            const int kind = global_late ? 1 - turn : turn;
             pm_map *map = kind == 0 ? gmap : cmap;
             if (rp->flags & (kind == 0 ? PM_FLAG_NO_GLOBAL : PM_FLAG_NO_CAUSTIC)) continue;
             // the map may still be under construction on its build stream (beside the passes above, and beside the other

@@ -230,8 +230,8 @@ __global__ __launch_bounds__(256) void k_cell_boxes_fine(const float4 *pos4, con
             lo[a] = min(lo[a], sub); hi[a] = max(hi[a], sub);
         }
     };
-    // a cell holding thousands of photons is a dense blob that queries split further anyway: its box is the whole cube
-    const bool huge = end - first > 4096u;
+    // a cell holding many hundreds of photons is a dense blob that queries split further anyway: its box is the whole cube
+    const bool huge = end - first > 512u;
     if (huge) { const uint32_t lo[3] = {0u, 0u, 0u}, hi[3] = {1023u, 1023u, 1023u}; cbox[box_off(lmax) + c] = pack_box(lo, hi); }
     const bool big = !huge && end - first > 32u;
     if (end > first && !big && !huge) {

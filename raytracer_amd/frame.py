@@ -136,7 +136,7 @@ class GpuFrame:
             if m is not None:
                 m.destroy()
         self.maps = [None, None]
-        for kind in (0, 1):
+        for kind in (1, 0):   # the caustic map takes longer (more attempts per photon): its build goes first
             if self.flags & (1 << kind):
                 continue
             if self.dist is None:
