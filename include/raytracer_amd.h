@@ -109,6 +109,19 @@ int pm_emit_range(pm_ctx *ctx, int32_t map_kind, uint64_t seed, const double lig
                   uint64_t attempt_begin, uint64_t attempt_count, pm_photon *d_out, uint64_t cap,
                   uint64_t *out_count);
 
+/* pm_emit_range for one rank of a multi-GPU job, without a wait: the shard is DEVICE memory of 32 + 32 * cap bytes, a
+ * 32-byte header {uint64 count, uint64 cap, 0, 0} followed by the first cap successes of the range in attempt order.
+ * count = successes in the range (it may exceed cap).  Everything is queued on the context's stream; the shards of all
+ * ranks are then exchanged with ONE all-gather (RCCL) and handed to pm_map_build_shards.  No counterpart in the
+ * reference (it has no ranks); the loop body is the one pm_emit_range cites. */
+int pm_emit_shard(pm_ctx *ctx, int32_t map_kind, uint64_t seed, const double light_color[3],
+                  uint64_t attempt_begin, uint64_t attempt_count, void *d_shard, uint64_t cap);
+
+/* createKDTree (src/PhotonMap.cpp:64-140) on the first n records, in rank order, of `world` shards laid out
+ * shard_stride bytes apart in DEVICE memory (the result of the all-gather).  Nothing waits: the first use of the map
+ * does, and fails with PM_ESTATE if the shards held fewer than n photons or one overflowed its cap. */
+int pm_map_build_shards(pm_ctx *ctx, const void *d_shards, int32_t world, uint64_t shard_stride, int64_t n, pm_map **out);
+
 /* createKDTree (src/PhotonMap.cpp:64-140): builds the spatial index (linear octree over
  * Morton-sorted photons) from n records in emission order.  records_on_device: 0 = host pointer, 1 = device. */
 int pm_map_build(pm_ctx *ctx, const pm_photon *records, int64_t n, int32_t records_on_device, pm_map **out);

@@ -51,7 +51,7 @@ class PMError(RuntimeError):
 
 
 EXPORTS = ["pm_ctx_create", "pm_ctx_destroy", "pm_ctx_set_stream", "pm_last_error", "pm_scene_upload",
-           "pm_emit_range", "pm_map_build", "pm_map_create", "pm_map_size", "pm_map_download", "pm_map_destroy",
+           "pm_emit_range", "pm_emit_shard", "pm_map_build", "pm_map_build_shards", "pm_map_create", "pm_map_size", "pm_map_download", "pm_map_destroy",
            "pm_knn_query", "pm_knn_profile", "pm_knn_gather", "pm_primary_hits", "pm_render"]
 
 _lib = None
@@ -78,6 +78,8 @@ def load_library():
         "pm_emit_range": [vp, i32, u64, C.POINTER(C.c_double), u64, u64, vp, u64, C.POINTER(u64)],
         "pm_map_build": [vp, vp, i64, i32, C.POINTER(vp)],
         "pm_map_create": [vp, i32, i64, u64, C.POINTER(C.c_double), C.POINTER(vp), C.POINTER(u64)],
+        "pm_emit_shard": [vp, i32, u64, C.POINTER(C.c_double), u64, u64, vp, u64],
+        "pm_map_build_shards": [vp, vp, i32, u64, i64, C.POINTER(vp)],
         "pm_map_size": [vp, C.POINTER(i64)], "pm_map_download": [vp, vp], "pm_map_destroy": [vp],
         "pm_knn_query": [vp, vp, i64, vp, vp, vp, vp],
         "pm_knn_profile": [vp, vp, i64, vp, vp, vp, vp, vp],
@@ -180,6 +182,16 @@ class Context:
         _check(self.lib.pm_emit_range(self.handle, kind, seed, _vec3(light_color), attempt_begin, attempt_count,
                                       C.c_void_p(d_out_ptr), cap, C.byref(cnt)))
         return cnt.value
+
+    def emit_shard(self, kind, seed, light_color, attempt_begin, attempt_count, d_shard_ptr, cap):
+        """pm_emit_range without a wait, into a shard (32-byte header + cap records) in DEVICE memory."""
+        _check(self.lib.pm_emit_shard(self.handle, kind, seed, _vec3(light_color), attempt_begin, attempt_count, C.c_void_p(d_shard_ptr), cap))
+
+    def build_map_shards(self, d_shards_ptr, world, shard_stride, kind, n):
+        """createKDTree on the first n records, in rank order, of the all-gathered shards (device memory).  No wait."""
+        h = C.c_void_p()
+        _check(self.lib.pm_map_build_shards(self.handle, C.c_void_p(d_shards_ptr), world, shard_stride, int(n), C.byref(h)))
+        return PhotonMap(self, h, kind)
 
     def build_map(self, records, kind, n=None, on_device=False):
         """createKDTree on n records: a numpy photon array, or a device pointer with on_device=True."""

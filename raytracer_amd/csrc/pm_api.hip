@@ -98,7 +98,7 @@ struct pm_map {
     bool pending = false;
     int slot = 2;
     hipEvent_t ready = nullptr;
-    uint64_t *h_got = nullptr;
+    uint64_t *h_got = nullptr;           // pinned, two words: photons available; a shard overflowed
     int kind = 0; uint64_t seed = 0, next_attempt = 0; double lc[3] = {0, 0, 0};
     DevBuf records, pos4, rest, cells, keys, cbox, grid;
     MapView view{};
@@ -251,6 +251,24 @@ extern "C" int pm_emit_range(pm_ctx *ctx, int32_t map_kind, uint64_t seed, const
     return emit_range(ctx, ctx->slot[2], map_kind, seed, light_color, attempt_begin, attempt_count, d_out, cap, ctx->h_u64, out_count);
 }
 
+extern "C" int pm_emit_shard(pm_ctx *ctx, int32_t map_kind, uint64_t seed, const double light_color[3], uint64_t attempt_begin,
+                             uint64_t attempt_count, void *d_shard, uint64_t cap) {
+    if (!ctx || !light_color || !d_shard) return fail(PM_EINVAL, "pm_emit_shard: NULL argument");
+    if (map_kind != PM_MAP_GLOBAL && map_kind != PM_MAP_CAUSTIC) return fail(PM_EINVAL, "pm_emit_shard: bad map_kind");
+    if (ctx->nprims == 0) return fail(PM_ESTATE, "pm_emit_shard: no scene uploaded");
+    PMCHK(set_device(ctx));
+    BuildSlot &sl = ctx->slot[2];
+    sl.stream = ctx->stream;
+    const uint64_t head[4] = {0, cap, 0, 0};
+    HIPCHK(hipMemcpyAsync(d_shard, head, sizeof(head), hipMemcpyHostToDevice, ctx->stream));
+    if (attempt_count == 0) return PM_OK;
+    PMCHK(emit_range(ctx, sl, map_kind, seed, light_color, attempt_begin, attempt_count, reinterpret_cast<pm_photon *>((char *)d_shard + 32), cap, ctx->h_u64, nullptr));
+    // the count of successes (it may exceed cap: pm_map_build_shards reports that) goes into the header, on the device
+    uint32_t nb = (uint32_t)((attempt_count + 255) / 256);
+    HIPCHK(hipMemcpyAsync(d_shard, sl.emit_offs.as<uint64_t>() + nb, 8, hipMemcpyDeviceToDevice, ctx->stream));
+    return PM_OK;
+}
+
 // ---------------------------------------------------------------------------------------- build
 static int build_index(pm_map *map, BuildSlot &sl) {
     long long n = map->n;
@@ -310,7 +328,7 @@ static pm_map *new_map(pm_ctx *ctx) {
     else m = new (std::nothrow) pm_map();
     if (!m) return nullptr;
     if (!m->ready && hipEventCreateWithFlags(&m->ready, hipEventDisableTiming) != hipSuccess) { delete m; return nullptr; }
-    if (!m->h_got && hipHostMalloc((void **)&m->h_got, sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) { (void)hipEventDestroy(m->ready); delete m; return nullptr; }
+    if (!m->h_got && hipHostMalloc((void **)&m->h_got, 2 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) { (void)hipEventDestroy(m->ready); delete m; return nullptr; }
     m->ctx = ctx; m->pending = false;
     return m;
 }
@@ -329,6 +347,11 @@ static int map_ready(pm_map *map) {
     pm_ctx *ctx = map->ctx;
     map->pending = false;
     if (hipEventSynchronize(map->ready) != hipSuccess) return fail(PM_EHIP, "photon map: emission or build failed on the device");
+    if (map->kind == -2) {             // assembled from shards: they must have held n photons, none cut off
+        if (map->h_got[1]) return fail(PM_ESTATE, "pm_map_build_shards: a shard overflowed its capacity");
+        if (*map->h_got < (uint64_t)map->n) return fail(PM_ESTATE, "pm_map_build_shards: the shards hold fewer than n photons");
+        return PM_OK;
+    }
     if (map->kind < 0) return PM_OK;   // built from records: nothing to check
     const uint64_t n = (uint64_t)map->n;
     uint64_t have = std::min<uint64_t>(*map->h_got, n);
@@ -370,6 +393,32 @@ extern "C" int pm_map_build(pm_ctx *ctx, const pm_photon *records, int64_t n, in
     if (rc == PM_OK) rc = take_slot(ctx, map->slot);
     if (rc == PM_OK) rc = build_index(map, ctx->slot[map->slot]);
     if (rc == PM_OK && hipEventRecord(map->ready, ctx->slot[map->slot].stream) != hipSuccess) rc = fail(PM_EHIP, "pm_map_build: hipEventRecord failed");
+    if (rc != PM_OK) { pm_map_destroy(map); return rc; }
+    map->pending = true;
+    *out = map;
+    return PM_OK;
+}
+
+extern "C" int pm_map_build_shards(pm_ctx *ctx, const void *d_shards, int32_t world, uint64_t shard_stride, int64_t n, pm_map **out) {
+    if (!ctx || !out || n < 0 || !d_shards || world < 1 || world > 64 || shard_stride < 32 || (shard_stride & 15))
+        return fail(PM_EINVAL, "pm_map_build_shards: bad argument (1..64 shards, stride a multiple of 16 bytes)");
+    PMCHK(set_device(ctx));
+    pm_map *map = new_map(ctx);
+    if (!map) return fail(PM_ENOMEM, "out of host memory");
+    map->n = n; map->kind = -2;
+    int rc = map->records.ensure((size_t)std::max<int64_t>(n, 1) * sizeof(pm_photon));
+    if (rc == PM_OK) rc = map->grid.ensure(sizeof(GridParams) + 16);
+    if (rc == PM_OK && n > 0) {
+        // assembled on the caller's stream (the caller may reuse the shards behind this call); the count check travels
+        // with the map and is made by its first use
+        unsigned long long *status = reinterpret_cast<unsigned long long *>(map->grid.as<char>() + sizeof(GridParams));
+        hipLaunchKernelGGL(k_assemble_shards, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, reinterpret_cast<const unsigned char *>(d_shards),
+                           (int)world, (unsigned long long)shard_stride, (long long)n, map->records.as<pm_photon>(), status);
+        if (hipMemcpyAsync(map->h_got, status, 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = fail(PM_EHIP, "pm_map_build_shards: copy failed");
+    } else if (rc == PM_OK) { map->h_got[0] = 0; map->h_got[1] = 0; }
+    if (rc == PM_OK) rc = take_slot(ctx, map->slot);
+    if (rc == PM_OK) rc = build_index(map, ctx->slot[map->slot]);
+    if (rc == PM_OK && hipEventRecord(map->ready, ctx->slot[map->slot].stream) != hipSuccess) rc = fail(PM_EHIP, "pm_map_build_shards: hipEventRecord failed");
     if (rc != PM_OK) { pm_map_destroy(map); return rc; }
     map->pending = true;
     *out = map;

@@ -139,6 +139,33 @@ __global__ __launch_bounds__(256) void k_emit_scatter(const pm_photon *tmp, cons
     }
 }
 
+// ------------------------------------------------------------------ shards of a map emitted by several ranks
+// A shard: 32-byte header {count, cap, 0, 0} + cap records.  The map is the first n records in rank order.
+// status[0] = photons available (sum of counts), status[1] = 1 when a shard overflowed its cap.
+__global__ __launch_bounds__(256) void k_assemble_shards(const unsigned char *shards, int world, unsigned long long stride, long long n, pm_photon *out,
+                                                          unsigned long long *status) {
+    __shared__ unsigned long long first[65];
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0, over = 0;
+        for (int r = 0; r < world; r++) {
+            const unsigned long long *h = reinterpret_cast<const unsigned long long *>(shards + (size_t)r * stride);
+            first[r] = run;
+            if (h[0] > h[1]) over = 1;
+            run += h[0] < h[1] ? h[0] : h[1];
+        }
+        first[world] = run;
+        if (blockIdx.x == 0) { status[0] = run; status[1] = over; }
+    }
+    __syncthreads();
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || (unsigned long long)i >= first[world]) return;
+    int r = 0;
+    while (first[r + 1] <= (unsigned long long)i) r++;
+    const uint4 *src = reinterpret_cast<const uint4 *>(shards + (size_t)r * stride + 32) + 2 * ((unsigned long long)i - first[r]);
+    uint4 *dst = reinterpret_cast<uint4 *>(out + i);
+    dst[0] = src[0]; dst[1] = src[1];
+}
+
 // ------------------------------------------------------------------ index build
 __device__ inline uint32_t f2ord(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ inline float ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }

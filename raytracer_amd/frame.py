@@ -116,6 +116,8 @@ class GpuFrame:
         self.pane = torch.zeros((height, width), dtype=torch.int32, device=self.dev)
         self.maps = [None, None]
         self.last_stats = None
+        self._shard_bufs = {}       # kind -> (own shard, all shards), device byte tensors reused across frames
+        self._fast_shards = dist is not None and hasattr(dist, "all_gather_into_tensor")
 
     # --- photon maps: createPhotonMap / createCausticPhotonMap, src/Raytrace.cpp:314-316
     def _emit_fn(self, kind):
@@ -130,8 +132,31 @@ class GpuFrame:
     def _allgather(self, mine):
         return allgather_records(self.dist, mine, self.world)
 
-    def build_maps(self):
+    def _build_map_from_shards(self, kind):
+        """The sharded build without a host wait: this rank's attempt range -> a shard (header + records) on the
+        device, ONE all-gather of the shards, assembly + index build queued behind it.  The ranges are sized so that
+        together they hold n photons with room to spare; if they do not after all, the first use of the map raises and
+        ``render`` falls back to ``emit_sharded`` (rounds of ranges with the counts on the host)."""
         torch = self.torch
+        per = (batch_attempts(self.n, kind, self.world) + self.world - 1) // self.world
+        cap = int(per * (YIELD_EST[kind] + 0.10)) + 1024
+        nbytes = 32 + 32 * cap
+        bufs = self._shard_bufs.get(kind)
+        if bufs is None or bufs[0].numel() != nbytes:
+            bufs = (torch.empty(nbytes, dtype=torch.uint8, device=self.dev), torch.empty(nbytes * self.world, dtype=torch.uint8, device=self.dev))
+            self._shard_bufs[kind] = bufs
+        mine, every = bufs
+        self.ctx.emit_shard(kind, self.seed, self.light_color, self.rank * per, per, mine.data_ptr(), cap)
+        self.dist.all_gather_into_tensor(every, mine)
+        return self.ctx.build_map_shards(every.data_ptr(), self.world, nbytes, kind, self.n)
+
+    def _build_map_by_rounds(self, kind):
+        torch = self.torch
+        chunks, _ = emit_sharded(self.n, kind, self.world, self.rank, self._emit_fn(kind), self._allgather)
+        rec = torch.cat(chunks) if len(chunks) != 1 else chunks[0].contiguous()
+        return self.ctx.build_map(rec.data_ptr(), kind, n=self.n, on_device=True)
+
+    def build_maps(self, fast=True):
         for m in self.maps:
             if m is not None:
                 m.destroy()
@@ -141,15 +166,24 @@ class GpuFrame:
                 continue
             if self.dist is None:
                 self.maps[kind] = self.ctx.create_map(kind, self.n, self.seed, self.light_color, wait=False)
+            elif fast and self._fast_shards:
+                self.maps[kind] = self._build_map_from_shards(kind)
             else:
-                chunks, _ = emit_sharded(self.n, kind, self.world, self.rank, self._emit_fn(kind), self._allgather)
-                rec = torch.cat(chunks) if len(chunks) != 1 else chunks[0].contiguous()
-                self.maps[kind] = self.ctx.build_map(rec.data_ptr(), kind, n=self.n, on_device=True)
+                self.maps[kind] = self._build_map_by_rounds(kind)
 
     # --- the job loop + waitForCompletion, src/Raytrace.cpp:322-336
     def render(self):
+        from .capi import PMError
         rp = self.ctx.params(self.w, self.h, self.seed, self.cam, self.light_color, self.flags, self.rank, self.world)
-        _, st = self.ctx.render(self.maps[0], self.maps[1], rp, d_pane=self.pane.data_ptr())
+        try:
+            _, st = self.ctx.render(self.maps[0], self.maps[1], rp, d_pane=self.pane.data_ptr())
+        except PMError as e:
+            if self.dist is None or "pm_map_build_shards" not in str(e):
+                raise
+            # the shards did not hold n photons (every rank sees the same counts, so every rank lands here)
+            self._fast_shards = False
+            self.build_maps(fast=False)
+            _, st = self.ctx.render(self.maps[0], self.maps[1], rp, d_pane=self.pane.data_ptr())
         self.last_stats = st
         return st
 

@@ -98,3 +98,49 @@ def test_emission_shortfall_is_repaired():
         hip.hipFree(d)
     finally:
         ctx.close()
+
+
+def _shards(ctx, hip, kind, n, seed, world, per, cap):
+    """`world` ranks' shards of attempt ranges of `per` attempts, laid out as the all-gather would (one device buffer)."""
+    stride = 32 + 32 * cap
+    d = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(d), stride * world) == 0
+    for r in range(world):
+        ctx.emit_shard(kind, seed, (0.6, 0.6, 0.6), r * per, per, d.value + r * stride, cap)
+    return d, stride
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_map_from_shards_is_the_single_rank_map(gpu_ctx, kind):
+    """Three ranks' attempt ranges, emitted without a wait and assembled on the device, give the very map one rank
+    emits alone (the map does not depend on the number of GPUs)."""
+    hip = ctypes.CDLL("libamdhip64.so")
+    n, seed, world = 30000, 11, 3
+    per = (int(n / (0.60 if kind == 0 else 0.36)) + 4096 * world + world - 1) // world
+    cap = int(per * ((0.60 if kind == 0 else 0.36) + 0.10)) + 1024
+    d, stride = _shards(gpu_ctx, hip, kind, n, seed, world, per, cap)
+    m = gpu_ctx.build_map_shards(d.value, world, stride, kind, n)
+    one = gpu_ctx.create_map(kind, n, seed)
+    assert np.array_equal(m.download().view(np.uint8), one.download().view(np.uint8))
+    pts = np.random.default_rng(3).uniform([-5, -5, 0], [5, 5, 10], size=(300, 3))
+    fa, ia, da = gpu_ctx.knn_query(m, pts)
+    fb, ib, db = gpu_ctx.knn_query(one, pts)
+    assert np.array_equal(fa, fb) and np.array_equal(ia, ib) and np.array_equal(da.view(np.uint64), db.view(np.uint64))
+    m.destroy(); one.destroy(); hip.hipFree(d)
+
+
+def test_map_from_shards_reports_shortfall_and_overflow(gpu_ctx):
+    import raytracer_amd as ra
+    hip = ctypes.CDLL("libamdhip64.so")
+    # too few attempts for n photons
+    d, stride = _shards(gpu_ctx, hip, 0, 10000, 3, 2, 2000, 4096)
+    m = gpu_ctx.build_map_shards(d.value, 2, stride, 0, 10000)
+    with pytest.raises(ra.PMError, match="fewer than n photons"):
+        m.download()
+    m.destroy(); hip.hipFree(d)
+    # enough attempts, but shards too small to hold their successes
+    d, stride = _shards(gpu_ctx, hip, 0, 10000, 3, 2, 12000, 1000)
+    m = gpu_ctx.build_map_shards(d.value, 2, stride, 0, 10000)
+    with pytest.raises(ra.PMError, match="overflowed"):
+        m.download()
+    m.destroy(); hip.hipFree(d)
