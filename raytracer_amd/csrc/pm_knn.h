@@ -254,15 +254,25 @@ __device__ inline void knn_reduce(KnnState &st) {
     PM_T1(t_red)
 }
 
-// One photon's term of the radiance sums: src/Raytrace.cpp:100-125 (global), :139-164 (caustic)
+// x / 255.0 for an integer 0 <= x <= 255, correctly rounded, without the division: the product with the rounded
+// reciprocal is off by one ulp for 24 of the 256 values, one Newton step with exact residual (fma) repairs all of them
+// (checked exhaustively in exact arithmetic: tests/test_oracle_golden.py::test_byte_over_255_identity)
+__device__ inline double byte_over_255(int x) {
+    const double inv = 1.0 / 255.0, xd = (double)x;
+    double q = xd * inv;
+    double res = __builtin_fma(-q, 255.0, xd);
+    return __builtin_fma(res, inv, q);
+}
+
+// One photon's term of the radiance sums: src/Raytrace.cpp:100-125 (global), :139-164 (caustic).
+// s = shade point - photon position (the reference's `dist`), pd2 = |s|^2, r = the 63rd-smallest pd2.
 template <int KIND>
-__device__ inline void photon_term(const float4 &pp, const uint4 &rr, const V3 &p, const V3 &nrm, double pd2, double r,
-                                   double &tr, double &tg, double &tb) {
+__device__ inline void photon_term_s(double sx, double sy, double sz, const uint4 &rr, const V3 &nrm, double pd2, double r,
+                                     double &tr, double &tg, double &tb) {
     tr = tg = tb = 0.0;
     float pdx = __uint_as_float(rr.x), pdy = __uint_as_float(rr.y), pdz = __uint_as_float(rr.z);
     double d = -(nrm.x * (double)pdx + nrm.y * (double)pdy + nrm.z * (double)pdz);
     if (d <= 0) return;
-    double sx = p.x - (double)pp.x, sy = p.y - (double)pp.y, sz = p.z - (double)pp.z;
     // the plane filter with its dist.z quirk: NaN compares false -> photon kept
     double k = (sx * nrm.x + sy * nrm.y + sz * nrm.z) / (sz * sz + sz * sz + sz * sz);
     sx *= k; sy *= k; sz *= k;
@@ -272,16 +282,22 @@ __device__ inline void photon_term(const float4 &pp, const uint4 &rr, const V3 &
     int p0 = pw & 0xFF, p1 = (pw >> 8) & 0xFF, p2 = (pw >> 16) & 0xFF;
     if (KIND == 0) {
         filter = filter * filter;
-        tr = d * (p0 / 255.0) * filter;
-        tg = d * (p1 / 255.0) * filter;
-        tb = d * (p2 / 255.0) * filter;
+        tr = d * byte_over_255(p0) * filter;     // d * (power[0] / 255.0) * filter
+        tg = d * byte_over_255(p1) * filter;
+        tb = d * byte_over_255(p2) * filter;
     } else {
         filter = filter * filter * filter * filter;
-        // raytrace::min(int32,int32) on a truncated double: factor is 0 or 1
-        tr = d * filter * imin((int32_t)((double)(p0 / 255.0f) + 0.5), 1);
-        tg = d * filter * imin((int32_t)((double)(p1 / 255.0f) + 0.5), 1);
-        tb = d * filter * imin((int32_t)((double)(p2 / 255.0f) + 0.5), 1);
+        // raytrace::min(int32,int32) on a truncated double: min((int)((double)(p / 255.0f) + 0.5), 1) is 1 for
+        // p >= 128 and 0 below (checked for all 256 values, same test)
+        tr = d * filter * (double)(p0 >= 128);
+        tg = d * filter * (double)(p1 >= 128);
+        tb = d * filter * (double)(p2 >= 128);
     }
+}
+template <int KIND>
+__device__ inline void photon_term(const float4 &pp, const uint4 &rr, const V3 &p, const V3 &nrm, double pd2, double r,
+                                   double &tr, double &tg, double &tb) {
+    photon_term_s<KIND>(p.x - (double)pp.x, p.y - (double)pp.y, p.z - (double)pp.z, rr, nrm, pd2, r, tr, tg, tb);
 }
 
 __device__ inline int grid_query(KnnState &st, KnnBuf *buf, const MapView &m, const V3 &q, double &r, double lim0);   // pm_grid.h

@@ -374,7 +374,9 @@ __device__ inline bool tile_gather(TileBuf *tb, const Strip &S, const MapView &m
     auto term = [&](int k, const float4 &s, const uint4 &rr) {
         if (k < mc) {
             double tr, tg, tb_;
-            photon_term<KIND>(s, rr, p, nrm, tile_d2(s, p), r, tr, tg, tb_);
+            // d2 as everywhere (photon - point, three squares summed left to right); the term wants point - photon: the negation is exact
+            const double ddx = (double)s.x - p.x, ddy = (double)s.y - p.y, ddz = (double)s.z - p.z;
+            photon_term_s<KIND>(-ddx, -ddy, -ddz, rr, nrm, ddx * ddx + ddy * ddy + ddz * ddz, r, tr, tg, tb_);
             if (tr != 0.0) aR += (long long)(tr * FX_SCALE);
             if (tg != 0.0) aG += (long long)(tg * FX_SCALE);
             if (tb_ != 0.0) aB += (long long)(tb_ * FX_SCALE);

@@ -153,3 +153,18 @@ def test_empty_and_tiny_maps(orc):
     f, idx, d2 = m.knn_exact([0, 0, 5])
     assert f == 10 and np.all(np.diff(d2[:10]) >= 0)
     m.close()
+
+
+def test_byte_over_255_identity():
+    """The product's division-free x / 255.0 (pm_knn.h, byte_over_255) and its caustic power factor, for all 256 photon
+    power bytes, in exact arithmetic: q = fl(x * inv); res = fl(x - q * 255) (exact in an fma); fl(q + res * inv) must be
+    the correctly rounded quotient; min((int)((double)(float(x) / 255.0f) + 0.5), 1) must be x >= 128."""
+    from fractions import Fraction
+    inv = 1.0 / 255.0
+    for x in range(256):
+        q = x * inv
+        res = float(Fraction(x) - Fraction(q) * 255)
+        assert float(Fraction(q) + Fraction(res) * Fraction(inv)) == x / 255.0, x
+    xf = np.arange(256, dtype=np.float32)
+    factor = np.minimum(((xf / np.float32(255.0)).astype(np.float64) + 0.5).astype(np.int32), 1)
+    assert np.array_equal(factor, (np.arange(256) >= 128).astype(np.int32))
