@@ -277,9 +277,7 @@ __global__ __launch_bounds__(256) void k_cell_boxes_fine(const float4 *pos4, con
     }
 }
 // level l from level l + 1: union of the non-empty children, halved into the parent's 1/1024 slices
-__global__ __launch_bounds__(256) void k_cell_boxes_up(const uint32_t *cells, int l, uint64_t *cbox) {
-    long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= (1LL << (3 * l))) return;
+__device__ inline void cell_box_up(const uint32_t *cells, int l, long long c, uint64_t *cbox) {
     const uint32_t *tab = cells + cell_off(l + 1);
     uint32_t lo[3] = {1023u, 1023u, 1023u}, hi[3] = {0u, 0u, 0u};
     bool any = false;
@@ -295,6 +293,18 @@ __global__ __launch_bounds__(256) void k_cell_boxes_up(const uint32_t *cells, in
         }
     }
     if (any) cbox[box_off(l) + c] = pack_box(lo, hi);
+}
+__global__ __launch_bounds__(256) void k_cell_boxes_up(const uint32_t *cells, int l, uint64_t *cbox) {
+    long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < (1LL << (3 * l))) cell_box_up(cells, l, c, cbox);
+}
+// levels ltop, ltop - 1, ..., 0 in one block (8^ltop <= 4096 cells): one launch instead of one per level
+__global__ __launch_bounds__(1024) void k_cell_boxes_top(const uint32_t *cells, int ltop, uint64_t *cbox) {
+    for (int l = ltop; l >= 0; l--) {
+        for (long long c = threadIdx.x; c < (1LL << (3 * l)); c += blockDim.x) cell_box_up(cells, l, c, cbox);
+        __threadfence_block();
+        __syncthreads();
+    }
 }
 
 // sorted order -> the two 16-byte streams the gather reads

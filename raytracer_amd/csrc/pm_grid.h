@@ -23,7 +23,7 @@ __device__ inline uint32_t quant21(float p, float lo, float ext) {   // shared b
 }
 __device__ inline uint64_t morton63(uint32_t x, uint32_t y, uint32_t z) { return spread21(x) | (spread21(y) << 1) | (spread21(z) << 2); }
 
-constexpr int GRID_MAX_LEVEL = 16;   // cells are not split below this level: photons are sorted on the top 48 key bits only (pm_sort.hip)
+constexpr int GRID_MAX_LEVEL = 10;   // cells are not split below this level: photons are sorted on the top 30 key bits only (pm_sort.hip)
 #ifndef PM_GRID_SPLIT
 #define PM_GRID_SPLIT 128      // a queued cell holding more photons than this is split into its 8 children before it is read
 #endif
