@@ -29,6 +29,8 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_GATHER = 63 * 32      # k photon records of 32 B
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+WORKLOAD = {"default": "default Cornell scene", "spheres10k": "five walls + 10,000 diffuse spheres (BASELINE config 5 scene),",
+            "caustics": "five walls + five glass spheres (BASELINE config 4 scene),"}
 
 
 def pmc_traffic(kernel):
@@ -47,11 +49,10 @@ def pmc_traffic(kernel):
     return None, "no PMC summary found"
 
 
-def cpu_baseline(frame, args, cores):
+def cpu_baseline(frame, args, cores, scene):
     """Oracle ("port") on the host cores: every `stride`-th row of the same frame, same photon maps."""
     import numpy as np
     from oracle import orc_py
-    scene = orc_py.default_scene()
     gmap = orc_py.Map(frame.maps[0].download())
     cmap = orc_py.Map(frame.maps[1].download())
     rp = orc_py.params(args.width, args.height, args.seed)
@@ -78,6 +79,8 @@ def main():
     ap.add_argument("--height", type=int, default=1440)
     ap.add_argument("--photons", type=int, default=1000000)
     ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--scene", default="default", choices=["default", "spheres10k", "caustics"],
+                    help="default = BASELINE config 2 (the bench line); spheres10k / caustics = the synthetic scenes of configs 5 / 4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-stride", type=int, default=1)
     ap.add_argument("--cpu-cores", type=int, default=0)
@@ -108,7 +111,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     ctx = ra.Context(local_rank)
-    ctx.upload_scene(ra.default_scene())      # the input that is resident before the timed region
+    scene = {"default": ra.default_scene, "spheres10k": ra.many_spheres_scene, "caustics": ra.caustics_scene}[args.scene]()
+    ctx.upload_scene(scene)                   # the input that is resident before the timed region
     frame = GpuFrame(ctx, args.width, args.height, args.photons, args.seed, rank=rank, world=world,
                      dist=dist if use_dist else None)
 
@@ -162,8 +166,8 @@ def main():
             "value": rays / step_s / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"default Cornell scene {args.width}x{args.height}, 1 spp, {args.photons} global + {args.photons} caustic photons, "
-                                   f"k=63, 25 shadow rays, depth<=3 (BASELINE config 2); step = emit both maps + build indices + trace/shade + pane on rank 0",
+            "config": {"workload": f"{WORKLOAD[args.scene]} {args.width}x{args.height}, 1 spp, {args.photons} global + {args.photons} caustic photons, "
+                                   f"k=63, 25 shadow rays, depth<=3{' (BASELINE config 2)' if args.scene == 'default' else ''}; step = emit both maps + build indices + trace/shade + pane on rank 0",
                        "seed": args.seed, "parallelism": f"rows x{world} (16-row blocks), emission attempts x{world} + all-gather"},
             "gathers_per_s": gathers / step_s, "frame_time_s": step_s, "rays_per_frame": rays, "gathers_per_frame": gathers,
             "phases_ms_rank0": {**{k: v / args.steps for k, v in phase.items()}, "maps_enqueue_host_wall": t_maps / args.steps * 1e3},
@@ -174,7 +178,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             cores = args.cpu_cores or min(os.cpu_count() or 1, 16)
-            cb, cpane = cpu_baseline(frame, args, cores)
+            cb, cpane = cpu_baseline(frame, args, cores, scene)
             if args.check:
                 gp = frame.pane.cpu().numpy().view(np.uint32)
                 rows = slice(args.cpu_row_stride // 2, args.height, args.cpu_row_stride)

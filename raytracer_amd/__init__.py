@@ -9,3 +9,4 @@ from .capi import (  # noqa: F401
     PM_MAP_GLOBAL, PM_MAP_CAUSTIC, PM_FLAG_NO_GLOBAL, PM_FLAG_NO_CAUSTIC, PM_FLAG_NO_DIRECT,
     PMError, Context, PhotonMap, RenderParams, Stats, default_scene, prim_dtype, photon_dtype, load_library,
 )
+from .scenes import many_spheres_scene, caustics_scene  # noqa: F401,E402

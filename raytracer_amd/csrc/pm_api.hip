@@ -69,9 +69,9 @@ struct pm_ctx {
     hipEvent_t ev_g[2][3] = {};          // per map: gather begins, group kernel done, per-query kernel done
     // scene
     int nprims = 0, stride = 0;
-    bool lds = true;
+    int scene_mode = SCENE_LDS;   // SCENE_LDS: staged per block; SCENE_GLOBAL: read in place; SCENE_GRID: in place, through the sphere grid
     size_t scene_b = 0;
-    DevBuf scene;
+    DevBuf scene, sgrid;
     SceneView gv{};
     // frame work buffers (grow only, reused across frames)
     DevBuf geo, obj, pixel, node, tabslot, direct, radg, radc, color, clist, tab, ctr, pane, sched, groups, left, strips;
@@ -145,7 +145,7 @@ extern "C" int pm_ctx_destroy(pm_ctx *ctx) {
     for (int i = 0; i < 2; i++) if (ctx->slot[i].stream) { (void)hipStreamSynchronize(ctx->slot[i].stream); (void)hipStreamDestroy(ctx->slot[i].stream); }
     for (int i = 0; i < 3; i++) ctx->slot[i].release();
     if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
-    DevBuf *bufs[] = {&ctx->scene, &ctx->geo, &ctx->obj, &ctx->pixel, &ctx->node, &ctx->tabslot, &ctx->direct, &ctx->radg, &ctx->radc,
+    DevBuf *bufs[] = {&ctx->scene, &ctx->sgrid, &ctx->geo, &ctx->obj, &ctx->pixel, &ctx->node, &ctx->tabslot, &ctx->direct, &ctx->radg, &ctx->radc,
                       &ctx->color, &ctx->clist, &ctx->tab, &ctx->ctr, &ctx->pane, &ctx->sched, &ctx->groups, &ctx->left, &ctx->strips};
     for (DevBuf *b : bufs) b->release();
     for (pm_map *m : ctx->spare) free_map(m);
@@ -165,6 +165,96 @@ extern "C" int pm_ctx_set_stream(pm_ctx *ctx, void *hip_stream) {
     if (!ctx) return fail(PM_EINVAL, "ctx is NULL");
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
     return PM_OK;
+}
+
+// ------------------------------------------------------------------------------------ scene grid
+// Host-side build of the uniform grid over spheres (the scene is uploaded once, before any timed region).
+constexpr int SCENE_GRID_MIN_SPHERES = 64;     // fewer: the linear scan (from LDS when the scene fits) is as good
+constexpr int SCENE_GRID_MAX_RES = 256;        // cells per axis
+constexpr double SCENE_GRID_CELLS_PER_SPHERE = 4.0;
+constexpr long long SCENE_GRID_MAX_CELLS_PER_SPHERE = 512;   // a sphere touching more cells is tested with the planes
+struct HostSceneGrid {
+    std::vector<int> loose, refs;
+    std::vector<uint32_t> cell_start;
+    int res[3] = {1, 1, 1};
+    double lo[3] = {0, 0, 0}, hi[3] = {1, 1, 1}, cs[3] = {1, 1, 1};
+};
+static void build_scene_grid(const pm_prim *prims, int n, HostSceneGrid &hg) {
+    // box of everywhere the sphere can be for dt in [0,1] (SphereObject::intersect moves the centre by dt * velocity,
+    // src/Scene.cpp:90-92), padded far beyond the rounding of the walk
+    struct Box { double lo[3], hi[3]; bool ok; };
+    std::vector<Box> box(n);
+    double glo[3] = {1e300, 1e300, 1e300}, ghi[3] = {-1e300, -1e300, -1e300};
+    int ns = 0;
+    for (int i = 0; i < n; i++) {
+        const pm_prim &p = prims[i];
+        Box &b = box[i];
+        b.ok = false;
+        if (p.kind != 0) continue;
+        const double c[3] = {p.x, p.y, p.z}, v[3] = {p.dx, p.dy, p.dz};
+        double r = fabs(p.radius);
+        bool finite = std::isfinite(r);
+        for (int a = 0; a < 3; a++) finite = finite && std::isfinite(c[a]) && std::isfinite(v[a]) && fabs(c[a]) < 1e12 && fabs(v[a]) < 1e12;
+        if (!finite || r > 1e12) continue;
+        for (int a = 0; a < 3; a++) {
+            double c1 = c[a] + v[a];
+            double pad = 1e-6 * (r + fabs(v[a])) + 1e-9 * (1.0 + fabs(c[a]) + fabs(c1));
+            b.lo[a] = std::min(c[a], c1) - r - pad;
+            b.hi[a] = std::max(c[a], c1) + r + pad;
+            glo[a] = std::min(glo[a], b.lo[a]); ghi[a] = std::max(ghi[a], b.hi[a]);
+        }
+        b.ok = true;
+        ns++;
+    }
+    for (int i = 0; i < n; i++) if (!box[i].ok) hg.loose.push_back(i);     // planes, and spheres that are not finite
+    if (ns == 0) { hg.cell_start.assign(2, 0); return; }
+    double ext[3], vol = 1;
+    for (int a = 0; a < 3; a++) {
+        double pad = 1e-6 * (ghi[a] - glo[a]) + 1e-9;
+        glo[a] -= pad; ghi[a] += pad;
+        ext[a] = ghi[a] - glo[a];
+        vol *= ext[a];
+    }
+    double density = SCENE_GRID_CELLS_PER_SPHERE;
+    if (const char *e = getenv("PM_SCENE_GRID_DENSITY")) { double v = atof(e); if (v > 0.01 && v < 1000) density = v; }   // experiments
+    double cell = cbrt(vol / (density * ns));
+    for (int a = 0; a < 3; a++) {
+        int r = (int)ceil(ext[a] / cell);
+        hg.res[a] = std::max(1, std::min(SCENE_GRID_MAX_RES, r));
+        hg.lo[a] = glo[a]; hg.hi[a] = ghi[a];
+        hg.cs[a] = ext[a] / hg.res[a];
+    }
+    auto cell_range = [&](const Box &b, int a, int &i0, int &i1) {
+        i0 = (int)floor((b.lo[a] - hg.lo[a]) / hg.cs[a]); i1 = (int)floor((b.hi[a] - hg.lo[a]) / hg.cs[a]);
+        i0 = std::max(0, std::min(hg.res[a] - 1, i0)); i1 = std::max(0, std::min(hg.res[a] - 1, i1));
+    };
+    size_t ncell = (size_t)hg.res[0] * hg.res[1] * hg.res[2];
+    std::vector<uint32_t> count(ncell + 1, 0);
+    for (int pass = 0; pass < 2; pass++) {
+        for (int i = 0; i < n; i++) {
+            Box &b = box[i];
+            if (!b.ok) continue;
+            int x0, x1, y0, y1, z0, z1;
+            cell_range(b, 0, x0, x1); cell_range(b, 1, y0, y1); cell_range(b, 2, z0, z1);
+            if (pass == 0 && (long long)(x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1) > SCENE_GRID_MAX_CELLS_PER_SPHERE) {
+                b.ok = false; hg.loose.push_back(i);
+                continue;
+            }
+            for (int z = z0; z <= z1; z++) for (int y = y0; y <= y1; y++) for (int x = x0; x <= x1; x++) {
+                size_t c = ((size_t)z * hg.res[1] + y) * hg.res[0] + x;
+                if (pass == 0) count[c]++;
+                else hg.refs[count[c]++] = i;          // spheres arrive in index order: every cell's list is ascending
+            }
+        }
+        if (pass == 0) {
+            hg.cell_start.resize(ncell + 1);
+            uint32_t run = 0;
+            for (size_t c = 0; c < ncell; c++) { hg.cell_start[c] = run; run += count[c]; count[c] = hg.cell_start[c]; }
+            hg.cell_start[ncell] = run;
+            hg.refs.resize(run);
+        }
+    }
+    std::sort(hg.loose.begin(), hg.loose.end());
 }
 
 // ---------------------------------------------------------------------------------------- scene
@@ -197,19 +287,47 @@ extern "C" int pm_scene_upload(pm_ctx *ctx, const pm_prim *prims, int32_t n) {
     PMCHK(ctx->scene.ensure(bytes));
     HIPCHK(hipMemcpyAsync(ctx->scene.p, host.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->nprims = n; ctx->stride = stride; ctx->scene_b = bytes; ctx->lds = bytes <= LDS_SCENE_MAX;
+    ctx->nprims = n; ctx->stride = stride; ctx->scene_b = bytes;
+    ctx->scene_mode = bytes <= LDS_SCENE_MAX ? SCENE_LDS : SCENE_GLOBAL;
     unsigned char *d = ctx->scene.as<unsigned char>();
+    ctx->gv = SceneView{};
     ctx->gv.n = n; ctx->gv.stride = stride;
     ctx->gv.g = reinterpret_cast<const double *>(d);
     ctx->gv.rgb = reinterpret_cast<const float *>(d + (size_t)stride * G_NFIELDS * sizeof(double));
     ctx->gv.kind = reinterpret_cast<const int *>(d + (size_t)stride * (G_NFIELDS * sizeof(double) + 3 * sizeof(float)));
+    // many spheres: a uniform grid narrows down the primitives a ray is tested against (PM_SCENE_GRID=0: never, for A/B runs)
+    const char *sg = getenv("PM_SCENE_GRID");
+    int nspheres = 0;
+    for (int i = 0; i < n; i++) nspheres += prims[i].kind == 0;
+    if (nspheres >= SCENE_GRID_MIN_SPHERES && !(sg && sg[0] == '0')) {
+        HostSceneGrid hg;
+        build_scene_grid(prims, n, hg);
+        size_t b_loose = (hg.loose.size() * sizeof(int) + 255) & ~(size_t)255, b_start = (hg.cell_start.size() * sizeof(uint32_t) + 255) & ~(size_t)255;
+        size_t b_refs = hg.refs.size() * sizeof(int);
+        PMCHK(ctx->sgrid.ensure(b_loose + b_start + b_refs + 256));
+        unsigned char *gd = ctx->sgrid.as<unsigned char>();
+        if (!hg.loose.empty()) HIPCHK(hipMemcpyAsync(gd, hg.loose.data(), hg.loose.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(gd + b_loose, hg.cell_start.data(), hg.cell_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        if (!hg.refs.empty()) HIPCHK(hipMemcpyAsync(gd + b_loose + b_start, hg.refs.data(), b_refs, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        SceneGrid &G = ctx->gv.grid;
+        G.nloose = (int)hg.loose.size(); G.rx = hg.res[0]; G.ry = hg.res[1]; G.rz = hg.res[2];
+        G.loose = reinterpret_cast<const int *>(gd);
+        G.cell_start = reinterpret_cast<const uint32_t *>(gd + b_loose);
+        G.refs = reinterpret_cast<const int *>(gd + b_loose + b_start);
+        for (int a = 0; a < 3; a++) { G.lo[a] = hg.lo[a]; G.hi[a] = hg.hi[a]; G.cs[a] = hg.cs[a]; G.inv_cs[a] = 1.0 / hg.cs[a]; }
+        ctx->scene_mode = SCENE_GRID;
+        if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] scene grid %d x %d x %d, %zu refs for %d spheres, %zu loose primitives\n", G.rx, G.ry, G.rz,
+                                        hg.refs.size(), nspheres, hg.loose.size());
+    }
     return PM_OK;
 }
 
-#define LAUNCH_SCENE_ON(kern, grid, block, ctx, strm, ...)                                                        \
-    do {                                                                                                          \
-        if ((ctx)->lds) hipLaunchKernelGGL(kern<true>, grid, block, (ctx)->scene_b, strm, (ctx)->gv, __VA_ARGS__); \
-        else hipLaunchKernelGGL(kern<false>, grid, block, 0, strm, (ctx)->gv, __VA_ARGS__);                       \
+#define LAUNCH_SCENE_ON(kern, grid, block, ctx, strm, ...)                                                                  \
+    do {                                                                                                                    \
+        if ((ctx)->scene_mode == SCENE_LDS) hipLaunchKernelGGL(kern<SCENE_LDS>, grid, block, (ctx)->scene_b, strm, (ctx)->gv, __VA_ARGS__); \
+        else if ((ctx)->scene_mode == SCENE_GRID) hipLaunchKernelGGL(kern<SCENE_GRID>, grid, block, 0, strm, (ctx)->gv, __VA_ARGS__);       \
+        else hipLaunchKernelGGL(kern<SCENE_GLOBAL>, grid, block, 0, strm, (ctx)->gv, __VA_ARGS__);                           \
     } while (0)
 #define LAUNCH_SCENE(kern, grid, block, ctx, ...) LAUNCH_SCENE_ON(kern, grid, block, ctx, (ctx)->stream, __VA_ARGS__)
 

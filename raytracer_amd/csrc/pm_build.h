@@ -15,12 +15,12 @@ namespace pm {
 // stores a photon.  block_counts[b] = successes in block b (for the ordered compaction).
 constexpr int EMIT_MAX_BOUNCES = 64;   // the reference loops until absorb/miss; bounded here so every wave exits
 
-template <bool LDS>
+template <int MODE>
 __global__ __launch_bounds__(256) void k_emit(SceneView gs, int map_kind, uint64_t K, V3 light_color, uint64_t a0, uint64_t count,
                                                pm_photon *tmp, uint8_t *flag, uint32_t *block_counts) {
     extern __shared__ __align__(16) unsigned char smem[];
     SceneView sv = gs;
-    if (LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
+    if (MODE == SCENE_LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool stored = false;
     if (t < count) {
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_emit(SceneView gs, int map_kind, uint64
         V3 res = {0, 0, 0}, nrm = {0, 0, 0};
         while (bounces < EMIT_MAX_BOUNCES) {
             bounces++;
-            int obj = scene_intersect(sv, src, dir, exclude, 0.0, res, nrm);
+            int obj = scene_intersect<MODE>(sv, src, dir, exclude, 0.0, res, nrm);
             if (obj < 0) break;
             double chance = draw(IK, j++);
             if (bounces > 3) chance = 1;

@@ -78,12 +78,25 @@ enum { G_X = 0, G_Y, G_Z, G_RADIUS, G_DX, G_DY, G_DZ, G_MIN, G_MAX, G_ABSORB, G_
        G_TRANSMISSION, G_REFRACTION, G_NFIELDS };
 enum { PK_SPHERE = 0, PK_PLANE_X = 1, PK_PLANE_Y = 2, PK_PLANE_Z = 3, PK_NEVER = 4 };
 
+// Uniform grid over the spheres of a large scene (built on the host at pm_scene_upload).  It only narrows down WHICH
+// primitives a ray is tested against; the tests themselves and the choice among the hits are those of the linear scan.
+struct SceneGrid {
+    int nloose;                  // primitives tested one by one: planes, spheres too large for the grid or not finite
+    int rx, ry, rz;              // cells per axis
+    const int *loose;            // ascending primitive ids
+    const uint32_t *cell_start;  // [rx*ry*rz + 1] into refs
+    const int *refs;             // sphere ids of every cell whose padded box (swept over dt in [0,1]) touches the cell
+    double lo[3], hi[3], cs[3], inv_cs[3];
+};
+enum { SCENE_LDS = 0, SCENE_GLOBAL = 1, SCENE_GRID = 2 };   // how a kernel reads the scene
+
 struct SceneView {
     int n;            // primitives
     int stride;       // elements per field array
     const double *g;  // [G_NFIELDS][stride]
     const float *rgb; // [3][stride]
     const int *kind;  // [stride]  PK_*
+    SceneGrid grid;   // SCENE_GRID only
     __device__ double f(int field, int i) const { return g[field * stride + i]; }
 };
 // bytes of one staged scene with `stride` slots
@@ -91,8 +104,10 @@ __host__ __device__ inline size_t scene_bytes(int stride) {
     return (size_t)stride * (G_NFIELDS * sizeof(double) + 3 * sizeof(float) + sizeof(int));
 }
 
-// SphereObject::intersect, src/Scene.cpp:87-116
-__device__ inline bool sphere_intersect(const SceneView &s, int i, const V3 &o, const V3 &d, double dt, V3 &res, V3 &nrm) {
+// SphereObject::intersect, src/Scene.cpp:87-116, in two parts: the hit point, and the normal at it.  The reference
+// computes the normal of every hit; only the normal of the hit that wins is ever read, so it is computed once, for
+// the winner, from the same operands (same bits).
+__device__ inline bool sphere_hit(const SceneView &s, int i, const V3 &o, const V3 &d, double dt, V3 &res) {
     double x0 = s.f(G_X, i) + dt * s.f(G_DX, i);
     double y0 = s.f(G_Y, i) + dt * s.f(G_DY, i);
     double z0 = s.f(G_Z, i) + dt * s.f(G_DZ, i);
@@ -106,12 +121,17 @@ __device__ inline bool sphere_intersect(const SceneView &s, int i, const V3 &o, 
     if (t < 0) t = b + t; else t = b - t;
     if (t < 0) return false;
     res.x = d.x * t + o.x; res.y = d.y * t + o.y; res.z = d.z * t + o.z;
-    nrm.x = res.x - x0; nrm.y = res.y - y0; nrm.z = res.z - z0;
-    normalize(nrm);
     return true;
 }
+__device__ inline void sphere_normal(const SceneView &s, int i, double dt, const V3 &res, V3 &nrm) {
+    double x0 = s.f(G_X, i) + dt * s.f(G_DX, i);
+    double y0 = s.f(G_Y, i) + dt * s.f(G_DY, i);
+    double z0 = s.f(G_Z, i) + dt * s.f(G_DZ, i);
+    nrm.x = res.x - x0; nrm.y = res.y - y0; nrm.z = res.z - z0;
+    normalize(nrm);
+}
 // PlaneObject::intersect, src/Scene.cpp:135-193 (IEEE inf/NaN behaviour is load-bearing)
-__device__ inline bool plane_intersect(const SceneView &s, int kind, int i, const V3 &c, const V3 &r, V3 &res, V3 &nrm) {
+__device__ inline bool plane_hit(const SceneView &s, int kind, int i, const V3 &c, const V3 &r, V3 &res) {
     double mn = s.f(G_MIN, i), mx = s.f(G_MAX, i);
     if (kind == PK_PLANE_X) {
         double px = s.f(G_X, i);
@@ -123,7 +143,6 @@ __device__ inline bool plane_intersect(const SceneView &s, int kind, int i, cons
         double hy = c.y + mul * r.y;
         if (hy > mx || hy < mn) return false;
         res.x = px; res.y = hy; res.z = hz;
-        nrm.x = px < 0 ? 1 : -1; nrm.y = 0; nrm.z = 0;
         return true;
     } else if (kind == PK_PLANE_Y) {
         double py = s.f(G_Y, i);
@@ -135,7 +154,6 @@ __device__ inline bool plane_intersect(const SceneView &s, int kind, int i, cons
         double hx = c.x + mul * r.x;
         if (hx < mn || hx > mx) return false;
         res.x = hx; res.y = py; res.z = hz;
-        nrm.x = 0; nrm.y = py < 0 ? 1 : -1; nrm.z = 0;
         return true;
     } else if (kind == PK_PLANE_Z) {
         double pz = s.f(G_Z, i);
@@ -147,32 +165,152 @@ __device__ inline bool plane_intersect(const SceneView &s, int kind, int i, cons
         double hy = c.y + mul * r.y;
         if (hy < mn || hy > mx) return false;
         res.x = hx; res.y = hy; res.z = pz;
-        nrm.x = 0; nrm.y = 0; nrm.z = pz < 0 ? 1 : -1;
         return true;
     }
     return false;
 }
-__device__ inline bool prim_intersect(const SceneView &s, int i, const V3 &o, const V3 &d, double dt, V3 &res, V3 &nrm) {
-    int kind = s.kind[i];
-    if (kind == PK_SPHERE) return sphere_intersect(s, i, o, d, dt, res, nrm);
-    return plane_intersect(s, kind, i, o, d, res, nrm);
+__device__ inline void plane_normal(const SceneView &s, int kind, int i, V3 &nrm) {   // towards the origin, src/Scene.cpp:155,172,189
+    nrm.x = 0; nrm.y = 0; nrm.z = 0;
+    if (kind == PK_PLANE_X) nrm.x = s.f(G_X, i) < 0 ? 1 : -1;
+    else if (kind == PK_PLANE_Y) nrm.y = s.f(G_Y, i) < 0 ? 1 : -1;
+    else nrm.z = s.f(G_Z, i) < 0 ? 1 : -1;
 }
+__device__ inline bool prim_hit(const SceneView &s, int i, const V3 &o, const V3 &d, double dt, V3 &res) {
+    int kind = s.kind[i];
+    if (kind == PK_SPHERE) return sphere_hit(s, i, o, d, dt, res);
+    return plane_hit(s, kind, i, o, d, res);
+}
+__device__ inline void prim_normal(const SceneView &s, int i, double dt, const V3 &res, V3 &nrm) {
+    int kind = s.kind[i];
+    if (kind == PK_SPHERE) sphere_normal(s, i, dt, res, nrm);
+    else plane_normal(s, kind, i, nrm);
+}
+// one axis of the clip against the grid's box; false = the ray misses the box
+__device__ inline bool grid_clip(double lo, double hi, double o, double d, double &inv, double &t0, double &t1) {
+    if (d != 0) {
+        inv = 1.0 / d;
+        double ta = (lo - o) * inv, tb = (hi - o) * inv;
+        double tn = ta < tb ? ta : tb, tf = ta < tb ? tb : ta;
+        if (tn > t0) t0 = tn;
+        if (tf < t1) t1 = tf;
+        return true;
+    }
+    inv = __builtin_inf();
+    return !(o < lo || o > hi);
+}
+// cell index of the entry point along one axis (NaN -> 0) and the parameter at which the ray leaves that cell
+__device__ inline int grid_enter(double lo, double cs, double inv_cs, int res, double o, double d, double inv, double t0, double &tnext) {
+    double f = ((o + d * t0) - lo) * inv_cs;
+    int i = f > 0 ? (f < (double)res ? (int)f : res - 1) : 0;
+    tnext = d != 0 ? (lo + (double)(i + (d > 0 ? 1 : 0)) * cs - o) * inv : __builtin_inf();
+    return i;
+}
+template <class F>
+__device__ inline void grid_walk(const SceneGrid &G, const V3 &o, const V3 &d, F &&visit) {
+    double t0 = 0, t1 = __builtin_inf(), invx, invy, invz;
+    if (!grid_clip(G.lo[0], G.hi[0], o.x, d.x, invx, t0, t1)) return;
+    if (!grid_clip(G.lo[1], G.hi[1], o.y, d.y, invy, t0, t1)) return;
+    if (!grid_clip(G.lo[2], G.hi[2], o.z, d.z, invz, t0, t1)) return;
+    if (!(t0 <= t1)) return;
+    double tx, ty, tz;
+    int ix = grid_enter(G.lo[0], G.cs[0], G.inv_cs[0], G.rx, o.x, d.x, invx, t0, tx);
+    int iy = grid_enter(G.lo[1], G.cs[1], G.inv_cs[1], G.ry, o.y, d.y, invy, t0, ty);
+    int iz = grid_enter(G.lo[2], G.cs[2], G.inv_cs[2], G.rz, o.z, d.z, invz, t0, tz);
+    const int sx = d.x > 0 ? 1 : -1, sy = d.y > 0 ? 1 : -1, sz = d.z > 0 ? 1 : -1;
+    double t_in = t0;
+    for (int guard = G.rx + G.ry + G.rz + 3; guard > 0; guard--) {
+        uint32_t c = ((uint32_t)iz * (uint32_t)G.ry + (uint32_t)iy) * (uint32_t)G.rx + (uint32_t)ix;
+        uint32_t b = G.cell_start[c], e = G.cell_start[c + 1];
+        if (!visit(b, e, t_in)) return;
+        if (tx <= ty && tx <= tz) {
+            t_in = tx; ix += sx;
+            if (ix < 0 || ix >= G.rx) return;
+            tx = (G.lo[0] + (double)(ix + (sx > 0 ? 1 : 0)) * G.cs[0] - o.x) * invx;
+        } else if (ty <= tz) {
+            t_in = ty; iy += sy;
+            if (iy < 0 || iy >= G.ry) return;
+            ty = (G.lo[1] + (double)(iy + (sy > 0 ? 1 : 0)) * G.cs[1] - o.y) * invy;
+        } else {
+            t_in = tz; iz += sz;
+            if (iz < 0 || iz >= G.rz) return;
+            tz = (G.lo[2] + (double)(iz + (sz > 0 ? 1 : 0)) * G.cs[2] - o.z) * invz;
+        }
+        if (!(t_in <= t1)) return;
+    }
+}
+
 // Scene::intersect, src/Scene.cpp:25-47: closest hit by squared distance of the reconstructed
 // hit point, strict '<' so the lowest index wins ties; returns object id or -1
+template <int MODE>
 __device__ inline int scene_intersect(const SceneView &s, const V3 &src, const V3 &dir, int exclude, double dt, V3 &fres, V3 &fnrm) {
     double nearest = 1024 * 1024;
     int nearest_obj = -1;
-    V3 res = {0, 0, 0}, nrm = {0, 0, 0};
-    for (int i = 0; i < s.n; i++) {
-        if (i == exclude) continue;
-        if (prim_intersect(s, i, src, dir, dt, res, nrm)) {
+    V3 res = {0, 0, 0};
+    if (MODE != SCENE_GRID) {
+        for (int i = 0; i < s.n; i++) {
+            if (i == exclude) continue;
+            if (prim_hit(s, i, src, dir, dt, res)) {
+                double dist = (res.x - src.x) * (res.x - src.x);
+                dist += (res.y - src.y) * (res.y - src.y);
+                dist += (res.z - src.z) * (res.z - src.z);
+                if (dist < nearest) { nearest = dist; nearest_obj = i; fres = res; }
+            }
+        }
+        if (nearest_obj >= 0) prim_normal(s, nearest_obj, dt, fres, fnrm);
+        return nearest_obj;
+    }
+    // The same minimum over (dist, index), with the candidates in another order: a later candidate wins only with a
+    // smaller distance, or the same distance and a lower index -- what the strict '<' of the index-order scan yields.
+    auto candidate = [&](int i) {
+        if (i == exclude) return;
+        if (prim_hit(s, i, src, dir, dt, res)) {
             double dist = (res.x - src.x) * (res.x - src.x);
             dist += (res.y - src.y) * (res.y - src.y);
             dist += (res.z - src.z) * (res.z - src.z);
-            if (dist < nearest) { nearest = dist; nearest_obj = i; fres = res; fnrm = nrm; }
+            if (dist < nearest || (dist == nearest && i < nearest_obj)) { nearest = dist; nearest_obj = i; fres = res; }
         }
-    }
+    };
+    const SceneGrid &G = s.grid;
+    for (int k = 0; k < G.nloose; k++) candidate(G.loose[k]);
+    double dd = dir.x * dir.x + dir.y * dir.y + dir.z * dir.z;    // 1 within rounding; kept for rays that are not
+    grid_walk(G, src, dir, [&](uint32_t b, uint32_t e, double t_in) {
+        // every hit from here on lies at parameter >= t_in: squared distance >= t_in^2 |dir|^2 (margin for rounding)
+        double far = t_in * (1.0 - 1e-9) - 1e-9;
+        if (far > 0 && far * far * dd > nearest) return false;
+        for (uint32_t r = b; r < e; r++) candidate(G.refs[r]);
+        return true;
+    });
+    if (nearest_obj >= 0) prim_normal(s, nearest_obj, dt, fres, fnrm);
     return nearest_obj;
+}
+
+// One shadow ray of the loop at src/Raytrace.cpp:190-203: is there a primitive other than `obj` with a hit whose squared
+// distance from p is not beyond max_dist (the first such primitive in index order ends the reference's loop; which one
+// it is does not matter).
+template <int MODE>
+__device__ inline bool shadow_blocked(const SceneView &s, const V3 &p, const V3 &ray, double dt, int obj, double max_dist) {
+    V3 result = {0, 0, 0};
+    auto blocks = [&](int k) {
+        if (k == obj) return false;
+        if (!prim_hit(s, k, p, ray, dt, result)) return false;
+        double ds = (p.x - result.x) * (p.x - result.x) + (p.y - result.y) * (p.y - result.y) + (p.z - result.z) * (p.z - result.z);
+        return !(ds > max_dist);
+    };
+    if (MODE != SCENE_GRID) {
+        for (int k = 0; k < s.n; k++) if (blocks(k)) return true;
+        return false;
+    }
+    const SceneGrid &G = s.grid;
+    for (int k = 0; k < G.nloose; k++) if (blocks(G.loose[k])) return true;
+    double dd = ray.x * ray.x + ray.y * ray.y + ray.z * ray.z;
+    bool hit = false;
+    grid_walk(G, p, ray, [&](uint32_t b, uint32_t e, double t_in) {
+        double far = t_in * (1.0 - 1e-9) - 1e-9;
+        if (far > 0 && far * far * dd > max_dist) return false;
+        for (uint32_t r = b; r < e; r++) if (blocks(G.refs[r])) { hit = true; return false; }
+        return true;
+    });
+    return hit;
 }
 
 // Stage the SoA scene into LDS (all threads of the block call this, then __syncthreads()).
@@ -181,8 +319,7 @@ __device__ inline SceneView stage_scene(const SceneView &gs, unsigned char *lds)
     const uint32_t *src = reinterpret_cast<const uint32_t *>(gs.g);  // g, rgb, kind are one contiguous block
     uint32_t *dst = reinterpret_cast<uint32_t *>(lds);
     for (size_t w = threadIdx.x + (size_t)threadIdx.y * blockDim.x; w < bytes / 4; w += (size_t)blockDim.x * blockDim.y) dst[w] = src[w];
-    SceneView v;
-    v.n = gs.n; v.stride = gs.stride;
+    SceneView v = gs;
     v.g = reinterpret_cast<const double *>(lds);
     v.rgb = reinterpret_cast<const float *>(lds + (size_t)gs.stride * G_NFIELDS * sizeof(double));
     v.kind = reinterpret_cast<const int *>(lds + (size_t)gs.stride * (G_NFIELDS * sizeof(double) + 3 * sizeof(float)));

@@ -78,11 +78,11 @@ __device__ inline bool tile_pixel(const FrameParams &fp, int &x, int &y) {
     return x < fp.width && y < fp.height;
 }
 
-template <bool LDS>
+template <int MODE>
 __global__ __launch_bounds__(256) void k_primary(SceneView gs, FrameParams fp, uint32_t *pane, Counters *ctr, SPQueue q, uint32_t *complex_list, uint2 *groups) {
     extern __shared__ __align__(16) unsigned char smem[];
     SceneView sv = gs;
-    if (LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
+    if (MODE == SCENE_LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
     int x, y;
     bool valid = tile_pixel(fp, x, y);
     int lane = threadIdx.x & 63;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void k_primary(SceneView gs, FrameParams fp, u
         pixel = (uint32_t)x + (uint32_t)y * (uint32_t)fp.width;
         V3 ray = primary_ray(fp.width, fp.height, fp.cam, fp.K, pixel, x, y);
         double dt = draw(item_key(fp.K, (uint64_t)pixel * 32u + 1u), 0);   // traceRay's own draw, src/Raytrace.cpp:39
-        obj = scene_intersect(sv, fp.cam, ray, -1, dt, res, nrm);
+        obj = scene_intersect<MODE>(sv, fp.cam, ray, -1, dt, res, nrm);
         if (obj < 0) pane[pixel] = 0xFF000000u;
         else if (is_light_patch(res)) pane[pixel] = light_colour(fp.light);
         else if (sv.f(G_TRANSMISSION, obj) > 0 || sv.f(G_SPECULAR, obj) > 0) emit_cx = true;
@@ -124,11 +124,11 @@ __global__ __launch_bounds__(256) void k_primary(SceneView gs, FrameParams fp, u
 }
 
 // hit ids / points / normals only (parity gate for primary rays)
-template <bool LDS>
+template <int MODE>
 __global__ __launch_bounds__(256) void k_primary_hits(SceneView gs, FrameParams fp, int y0, int y1, int32_t *ids, double *pts, double *nrms) {
     extern __shared__ __align__(16) unsigned char smem[];
     SceneView sv = gs;
-    if (LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
+    if (MODE == SCENE_LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long total = (long long)(y1 - y0) * fp.width;
     if (t >= total) return;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_primary_hits(SceneView gs, FrameParams 
     V3 ray = primary_ray(fp.width, fp.height, fp.cam, fp.K, pixel, x, y);
     double dt = draw(item_key(fp.K, (uint64_t)pixel * 32u + 1u), 0);
     V3 res = {0, 0, 0}, nrm = {0, 0, 0};
-    int obj = scene_intersect(sv, fp.cam, ray, -1, dt, res, nrm);
+    int obj = scene_intersect<MODE>(sv, fp.cam, ray, -1, dt, res, nrm);
     ids[t] = obj;
     if (pts) { pts[3 * t] = res.x; pts[3 * t + 1] = res.y; pts[3 * t + 2] = res.z; }
     if (nrms) { nrms[3 * t] = nrm.x; nrms[3 * t + 1] = nrm.y; nrms[3 * t + 2] = nrm.z; }
@@ -147,12 +147,12 @@ __global__ __launch_bounds__(256) void k_primary_hits(SceneView gs, FrameParams 
 //   a: 0 = not visited, 1 = constant colour in b, 2 = object (obj id in bits 8..) with absorb slot in b (0xFFFFFFFF = none)
 struct NodeEntry { uint32_t a, b; };
 
-template <bool LDS>
+template <int MODE>
 __global__ __launch_bounds__(256) void k_secondary(SceneView gs, FrameParams fp, Counters *ctr, SPQueue q, const uint32_t *complex_list,
                                                     uint32_t n_complex, NodeEntry *tab) {
     extern __shared__ __align__(16) unsigned char smem[];
     SceneView sv = gs;
-    if (LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
+    if (MODE == SCENE_LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
     uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_complex) return;
     uint32_t pixel = complex_list[c];
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_secondary(SceneView gs, FrameParams fp,
             double dt = draw(item_key(fp.K, (uint64_t)pixel * 32u + node), 0);
             if (depth > 0) nsec++;
             V3 res = {0, 0, 0}, nrm = {0, 0, 0};
-            int obj = scene_intersect(sv, src, ray, exclude, dt, res, nrm);
+            int obj = scene_intersect<MODE>(sv, src, ray, exclude, dt, res, nrm);
             if (obj < 0) { my[node].a = 1; my[node].b = 0xFF000000u; returned = true; }
             else if (is_light_patch(res)) { my[node].a = 1; my[node].b = light_colour(fp.light); returned = true; }
             else { fr[depth].hit = res; fr[depth].nrm = nrm; fr[depth].obj = obj; fr[depth].stage = 0; }
@@ -231,11 +231,11 @@ __global__ __launch_bounds__(256) void k_secondary(SceneView gs, FrameParams fp,
 }
 
 // shadow loop + direct term, src/Raytrace.cpp:174-212
-template <bool LDS>
+template <int MODE>
 __global__ __launch_bounds__(256) void k_shadow(SceneView gs, FrameParams fp, SPQueue q, uint32_t n_sp) {
     extern __shared__ __align__(16) unsigned char smem[];
     SceneView sv = gs;
-    if (LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
+    if (MODE == SCENE_LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_sp) return;
     V3 p = {q.geo[0 * (size_t)q.cap + s], q.geo[1 * (size_t)q.cap + s], q.geo[2 * (size_t)q.cap + s]};
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void k_shadow(SceneView gs, FrameParams fp, SP
     int obj = q.obj[s];
     uint64_t IK = item_key(fp.K, (uint64_t)q.pixel[s] * 32u + (q.node[s] & 31u));
     int light_count = 0;
-    V3 shadow_ray = {0, 0, 0}, result = {0, 0, 0}, normal = {0, 0, 0};
+    V3 shadow_ray = {0, 0, 0};
     for (int i = 0; i < 25; i++) {
         double x0 = draw(IK, 1 + 3 * i) * 2 - 1;
         double z0 = draw(IK, 2 + 3 * i) * 2 + 3;
@@ -252,15 +252,7 @@ __global__ __launch_bounds__(256) void k_shadow(SceneView gs, FrameParams fp, SP
         double max_dist = shadow_ray.x * shadow_ray.x + shadow_ray.y * shadow_ray.y + shadow_ray.z * shadow_ray.z;
         normalize(shadow_ray);
         double dt = draw(IK, 3 + 3 * i);
-        for (int k = 0; k < sv.n; k++) {
-            if (k == obj) continue;
-            if (prim_intersect(sv, k, p, shadow_ray, dt, result, normal)) {
-                double ds = (p.x - result.x) * (p.x - result.x) + (p.y - result.y) * (p.y - result.y) + (p.z - result.z) * (p.z - result.z);
-                if (ds > max_dist) continue;
-                light_count++;
-                break;
-            }
-        }
+        if (shadow_blocked<MODE>(sv, p, shadow_ray, dt, obj, max_dist)) light_count++;
     }
     double direct = 0;
     if (light_count < 25) {
@@ -469,11 +461,11 @@ __global__ __launch_bounds__(256) void k_knn_query(MapView m_in, const double *p
 }
 
 // clamp / colour / pack, src/Raytrace.cpp:230-242 ; simple pixels also get their final mix (:245-257)
-template <bool LDS>
+template <int MODE>
 __global__ __launch_bounds__(256) void k_shade(SceneView gs, FrameParams fp, SPQueue q, uint32_t n_sp, uint32_t *pane, NodeEntry *tab) {
     extern __shared__ __align__(16) unsigned char smem[];
     SceneView sv = gs;
-    if (LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
+    if (MODE == SCENE_LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_sp) return;
     int obj = q.obj[s];
@@ -494,11 +486,11 @@ __global__ __launch_bounds__(256) void k_shade(SceneView gs, FrameParams fp, SPQ
     else pane[q.pixel[s]] = mix_colour(0, 0, absorb_res, sv.f(G_SPECULAR, obj), sv.f(G_TRANSMISSION, obj), sv.f(G_ABSORB, obj));
 }
 
-template <bool LDS>
+template <int MODE>
 __global__ __launch_bounds__(256) void k_resolve(SceneView gs, const uint32_t *complex_list, uint32_t n_complex, const NodeEntry *tab, uint32_t *pane) {
     extern __shared__ __align__(16) unsigned char smem[];
     SceneView sv = gs;
-    if (LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
+    if (MODE == SCENE_LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
     uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_complex) return;
     const NodeEntry *my = tab + (size_t)c * 16;

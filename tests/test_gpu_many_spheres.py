@@ -1,6 +1,10 @@
 """GPU parity on a synthetic many-sphere scene (the shape of BASELINE config 5 at a size the oracle finishes in
-seconds): 400 primitives = 58 KB of scene, beyond the 48 KB the kernels stage in LDS, so every kernel takes its
-read-the-scene-from-global-memory variant.  Bars as everywhere: bit-exact hits, photons and panes against the oracle."""
+seconds): 400 primitives = 58 KB of scene, beyond the 48 KB the kernels stage in LDS, so every kernel reads the scene
+from global memory -- once through the sphere grid (the default for 64 spheres and more) and once by the linear scan
+(PM_SCENE_GRID=0).  Large, overlapping, partly moving spheres, mirrors and glass: the grid must never change a hit.
+Bars as everywhere: bit-exact hits, photons and panes against the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -31,13 +35,21 @@ def many_spheres(n_spheres=395, seed=17):
     return s
 
 
-@pytest.fixture(scope="module")
-def ctx_scene():
+@pytest.fixture(scope="module", params=["grid", "linear"])
+def ctx_scene(request):
     import raytracer_amd as ra
     scene = many_spheres()
     assert scene.nbytes > 48 * 1024
+    old = os.environ.get("PM_SCENE_GRID")
+    os.environ["PM_SCENE_GRID"] = "1" if request.param == "grid" else "0"      # read by pm_scene_upload
     ctx = ra.Context(0)
-    ctx.upload_scene(scene)
+    try:
+        ctx.upload_scene(scene)
+    finally:
+        if old is None:
+            del os.environ["PM_SCENE_GRID"]
+        else:
+            os.environ["PM_SCENE_GRID"] = old
     yield ctx, scene
     ctx.close()
 
