@@ -300,9 +300,25 @@ __device__ inline void photon_term(const float4 &pp, const uint4 &rr, const V3 &
     photon_term_s<KIND>(p.x - (double)pp.x, p.y - (double)pp.y, p.z - (double)pp.z, rr, nrm, pd2, r, tr, tg, tb);
 }
 
-__device__ inline int grid_query(KnnState &st, KnnBuf *buf, const MapView &m, const V3 &q, double &r, double lim0);   // pm_grid.h
-
 constexpr double FX_SCALE = 72057594037927936.0;   // 2^56
+
+// The same term as its three addends of the canonical sum: trunc(term * 2^56), per channel.  For the caustic map the three
+// channels are one value or nothing (the power factor is 0 or 1), so it is converted once.
+template <int KIND>
+__device__ inline void photon_term_fx(double sx, double sy, double sz, const uint4 &rr, const V3 &nrm, double pd2, double r,
+                                      long long &fr, long long &fg, long long &fb) {
+    double tr, tg, tb;
+    photon_term_s<KIND>(sx, sy, sz, rr, nrm, pd2, r, tr, tg, tb);
+    if (KIND == 0) {
+        fr = (long long)(tr * FX_SCALE); fg = (long long)(tg * FX_SCALE); fb = (long long)(tb * FX_SCALE);
+    } else {
+        // tr, tg, tb are each v = d * filter (times 1.0) or +0.0; max picks v when any channel has it
+        const long long v = (long long)(fmax(tr, fmax(tg, tb)) * FX_SCALE);
+        fr = tr != 0.0 ? v : 0; fg = tg != 0.0 ? v : 0; fb = tb != 0.0 ? v : 0;
+    }
+}
+
+__device__ inline int grid_query(KnnState &st, KnnBuf *buf, const MapView &m, const V3 &q, double &r, double lim0);   // pm_grid.h
 
 // A run of neighbouring queries hands the ball of one query to the next: 63 photons lie within sqrt(r) of `at`.
 struct KnnCarry { V3 at; double r; bool full; };
@@ -330,12 +346,12 @@ __device__ inline void knn_gather(KnnBuf *buf, const MapView &m, const V3 &p, co
             uint32_t i = buf->i[st.lane];
             float4 pp = m.pos4[i];
             uint4 rr = m.rest[i];
-            double tr, tg, tb;
-            photon_term<KIND>(pp, rr, p, nrm, d2, r, tr, tg, tb);
-            // order-independent sum: 64-bit fixed point, 2^-56 resolution (0 <= term <= 1, <= 63 terms)
-            if (tr != 0.0) atomicAdd(&buf->acc[0], (unsigned long long)(long long)(tr * FX_SCALE));
-            if (tg != 0.0) atomicAdd(&buf->acc[1], (unsigned long long)(long long)(tg * FX_SCALE));
-            if (tb != 0.0) atomicAdd(&buf->acc[2], (unsigned long long)(long long)(tb * FX_SCALE));
+            long long fr, fg, fb;
+            photon_term_fx<KIND>(p.x - (double)pp.x, p.y - (double)pp.y, p.z - (double)pp.z, rr, nrm, d2, r, fr, fg, fb);
+            // canonical order-independent sum: 64-bit fixed point in LDS
+            if (fr != 0) atomicAdd(&buf->acc[0], (unsigned long long)fr);
+            if (fg != 0) atomicAdd(&buf->acc[1], (unsigned long long)fg);
+            if (fb != 0) atomicAdd(&buf->acc[2], (unsigned long long)fb);
         }
     }
     wave_lds_fence();

@@ -305,14 +305,14 @@ __device__ inline bool tile_gather(TileBuf *tb, const Strip &S, const MapView &m
     });
     wave_lds_fence();
     int bstar = -1;
-    uint32_t cum = 0, below = 0;
+    uint32_t cum = 0;
 #pragma unroll
     for (int w = 0; w < TS_BINS / 4; w++) {
         uint32_t h = sel.hist[w * 64 + lane];
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             uint32_t c = (h >> (8 * b)) & 0xFFu;
-            if (bstar < 0 && cum + c >= (uint32_t)KNN_K) { bstar = 4 * w + b; below = cum; }
+            if (bstar < 0 && cum + c >= (uint32_t)KNN_K) bstar = 4 * w + b;
             cum += c;
         }
     }
@@ -373,13 +373,11 @@ __device__ inline bool tile_gather(TileBuf *tb, const Strip &S, const MapView &m
     auto index_of = [&](int k) -> uint32_t { return k < mc ? S.idx[sel.member[lane * TS_MROW + k]] : 0u; };
     auto term = [&](int k, const float4 &s, const uint4 &rr) {
         if (k < mc) {
-            double tr, tg, tb_;
+            long long fr, fg, fb;
             // d2 as everywhere (photon - point, three squares summed left to right); the term wants point - photon: the negation is exact
             const double ddx = (double)s.x - p.x, ddy = (double)s.y - p.y, ddz = (double)s.z - p.z;
-            photon_term_s<KIND>(-ddx, -ddy, -ddz, rr, nrm, ddx * ddx + ddy * ddy + ddz * ddz, r, tr, tg, tb_);
-            if (tr != 0.0) aR += (long long)(tr * FX_SCALE);
-            if (tg != 0.0) aG += (long long)(tg * FX_SCALE);
-            if (tb_ != 0.0) aB += (long long)(tb_ * FX_SCALE);
+            photon_term_fx<KIND>(-ddx, -ddy, -ddz, rr, nrm, ddx * ddx + ddy * ddy + ddz * ddz, r, fr, fg, fb);
+            aR += fr; aG += fg; aB += fb;
         }
     };
     uint32_t i0 = index_of(0), i1 = index_of(1), i2 = index_of(2), i3 = index_of(3);
