@@ -75,7 +75,11 @@ struct pm_ctx {
     SceneView gv{};
     // frame work buffers (grow only, reused across frames)
     DevBuf geo, obj, pixel, node, tabslot, direct, radg, radc, color, clist, tab, ctr, pane, sched, groups, left, strips;
+    DevBuf sp_keys_in, sp_keys_out, sp_vals_in, sp_vals_out, sp_sort_tmp, sp_bounds, sp_groups;   // spatial order of the bounced pixels' shade points
     bool use_tiles = true;     // PM_GATHER_TILE=0: every shade point goes through the per-query kernel (A/B switch)
+    double sp_cell = 6.0;      // cell size of those groups in 63-NN radii (PM_SP_CELL), and the shortest run worth a group (PM_SP_MIN_RUN)
+    int sp_min_run = 16;
+    bool group_bounced = true; // PM_GROUP_BOUNCED=0: the bounced pixels' shade points stay with the per-query kernel (A/B switch)
     int tile_blocks = 0, query_blocks = 0;   // resident blocks of the two gather kernels on this device
     uint32_t sp_cap = 0;
     Counters *h_ctr = nullptr;   // pinned
@@ -146,7 +150,8 @@ extern "C" int pm_ctx_destroy(pm_ctx *ctx) {
     for (int i = 0; i < 3; i++) ctx->slot[i].release();
     if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
     DevBuf *bufs[] = {&ctx->scene, &ctx->sgrid, &ctx->geo, &ctx->obj, &ctx->pixel, &ctx->node, &ctx->tabslot, &ctx->direct, &ctx->radg, &ctx->radc,
-                      &ctx->color, &ctx->clist, &ctx->tab, &ctx->ctr, &ctx->pane, &ctx->sched, &ctx->groups, &ctx->left, &ctx->strips};
+                      &ctx->color, &ctx->clist, &ctx->tab, &ctx->ctr, &ctx->pane, &ctx->sched, &ctx->groups, &ctx->left, &ctx->strips,
+                      &ctx->sp_keys_in, &ctx->sp_keys_out, &ctx->sp_vals_in, &ctx->sp_vals_out, &ctx->sp_sort_tmp, &ctx->sp_bounds, &ctx->sp_groups};
     for (DevBuf *b : bufs) b->release();
     for (pm_map *m : ctx->spare) free_map(m);
     ctx->spare.clear();
@@ -772,6 +777,10 @@ static int gather_blocks(pm_ctx *ctx) {
     ctx->query_blocks = std::max(8, std::max(1, per_cu_q) * cus / 8 * 8);
     const char *e = getenv("PM_GATHER_TILE");
     ctx->use_tiles = !(e && e[0] == '0');
+    const char *eb = getenv("PM_GROUP_BOUNCED");
+    ctx->group_bounced = !(eb && eb[0] == '0');
+    if (const char *v = getenv("PM_SP_CELL")) { double x = atof(v); if (x > 0.1 && x < 100) ctx->sp_cell = x; }
+    if (const char *v = getenv("PM_SP_MIN_RUN")) { int x = atoi(v); if (x >= 1 && x <= 64) ctx->sp_min_run = x; }
     if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] resident gather blocks: group kernel %d (%d per CU), per-query kernel %d (%d per CU), %d CUs\n", ctx->tile_blocks, per_cu_t,
                                     ctx->query_blocks, per_cu_q, cus);
     return PM_OK;
@@ -833,7 +842,7 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
     int n_gathers = 0;
     bool gathered[2] = {false, false};
-    uint32_t n_primary_sp = 0;
+    uint32_t n_primary_sp = 0, n_sorted = 0;
     if (n_sp) {
         LAUNCH_SCENE(k_shadow, dim3((n_sp + 255) / 256), block, ctx, fp, q, n_sp);
         HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
@@ -842,24 +851,54 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
         // as many blocks as the device keeps resident and draw their work from device counters.
         PMCHK(gather_blocks(ctx));
         PMCHK(ctx->sched.ensure(6 * SCHED_WORDS * 4 + 2 * 8192 * 16));
-        PMCHK(ctx->left.ensure((size_t)2 * n_sp0 * 4 + 8));
+        PMCHK(ctx->left.ensure((size_t)2 * n_sp * 4 + 8));
         PMCHK(ctx->strips.ensure((size_t)2 * ctx->tile_blocks * TS_STRIDE * sizeof(float4)));
         HIPCHK(hipMemsetAsync(ctx->sched.p, 0, 6 * SCHED_WORDS * 4, ctx->stream));   // 64 work counters per gather launch
         uint32_t *sched = ctx->sched.as<uint32_t>();
         uint32_t *left = ctx->left.as<uint32_t>();
         const bool use_tiles = ctx->use_tiles && n_sp0 > 0;
-        n_primary_sp = use_tiles ? n_sp0 : 0u;
         const int dbg = getenv("PM_DEBUG") ? 1 : 0;
-        // without the group kernel every shade point is in the per-query kernel's range: it simply starts at 0
-        const uint32_t sec_lo = use_tiles ? n_sp0 : 0u, sec_n = n_sp - sec_lo;
-        // Three streams side by side, so that the thin end of one launch (few items left, most CUs idle) is filled by the
-        // others: the global map's groups on the caller's stream, the caustic map's groups on a second, and on a third the
-        // per-query gather of the bounced pixels' shade points (no spatial order: never grouped) for both maps.  Each group
-        // kernel is followed, on its stream, by the per-query kernel for what it left.
+        // The shade points of bounced pixels (slots n_sp0 .. n_sp) in spatial order, for the group kernel; queued before the
+        // wait for the maps, whose builds this overlaps.
+        const bool sort_bounced = use_tiles && ctx->group_bounced && n_sp > n_sp0;
+        n_sorted = sort_bounced ? n_sp - n_sp0 : 0u;
+        if (sort_bounced) {
+            PMCHK(ctx->sp_keys_in.ensure((size_t)n_sorted * 8)); PMCHK(ctx->sp_keys_out.ensure((size_t)n_sorted * 8));
+            PMCHK(ctx->sp_vals_in.ensure((size_t)n_sorted * 4)); PMCHK(ctx->sp_vals_out.ensure((size_t)n_sorted * 4));
+            PMCHK(ctx->sp_bounds.ensure(6 * 4));
+            HIPCHK(hipMemsetAsync(ctx->sp_bounds.p, 0xFF, 12, ctx->stream));                                   // minima
+            HIPCHK(hipMemsetAsync(ctx->sp_bounds.as<unsigned char>() + 12, 0, 12, ctx->stream));             // maxima
+            hipLaunchKernelGGL(k_sp_bounds, dim3(std::min(256u, (n_sorted + 255) / 256)), block, 0, ctx->stream, q, n_sp0, n_sorted, ctx->sp_bounds.as<uint32_t>());
+            hipLaunchKernelGGL(k_sp_morton, dim3((n_sorted + 255) / 256), block, 0, ctx->stream, q, n_sp0, n_sorted, ctx->sp_bounds.as<uint32_t>(),
+                               ctx->sp_keys_in.as<uint64_t>(), ctx->sp_vals_in.as<uint32_t>());
+            size_t tmp_bytes = 0;
+            HIPCHK(sort_pairs_u64(nullptr, tmp_bytes, ctx->sp_keys_in.as<uint64_t>(), ctx->sp_keys_out.as<uint64_t>(), ctx->sp_vals_in.as<uint32_t>(),
+                                  ctx->sp_vals_out.as<uint32_t>(), (size_t)n_sorted, ctx->stream));
+            PMCHK(ctx->sp_sort_tmp.ensure(tmp_bytes));
+            HIPCHK(sort_pairs_u64(ctx->sp_sort_tmp.p, tmp_bytes, ctx->sp_keys_in.as<uint64_t>(), ctx->sp_keys_out.as<uint64_t>(), ctx->sp_vals_in.as<uint32_t>(),
+                                  ctx->sp_vals_out.as<uint32_t>(), (size_t)n_sorted, ctx->stream));
+            // cells of about six 63-NN radii (measured best on the default scene; most runs are then left to the tile kernel's own
+            // test of how far a group is spread): r^2 = 63 / (pi * density), density = photons / surface, surface taken as that
+            // of a cube over the points' extent (the sparser of the two maps decides)
+            long long n_ph = std::max<long long>(1, std::min(gmap ? gmap->n : (1LL << 40), cmap ? cmap->n : (1LL << 40)));
+            double cell_rel = ctx->sp_cell * sqrt(63.0 * 6.0 / (3.14159265 * (double)n_ph));
+            PMCHK(ctx->sp_groups.ensure((size_t)n_sorted * sizeof(uint2)));
+            hipLaunchKernelGGL(k_sp_groups, dim3((n_sorted + 255) / 256), block, 0, ctx->stream, ctx->sp_keys_out.as<uint64_t>(), ctx->sp_vals_out.as<uint32_t>(), n_sorted,
+                               cell_rel, (uint32_t)ctx->sp_min_run, ctx->sp_groups.as<uint2>(), d_ctr, left, left + n_sp);
+        }
+        const uint32_t *sorted = ctx->sp_vals_out.as<uint32_t>();
+        n_primary_sp = use_tiles ? n_sp0 + n_sorted : 0u;
+        // what the group kernel does not take is the per-query kernel's range: everything without the group kernel, the
+        // bounced pixels' shade points when they are not grouped, else nothing but what the group kernel leaves
+        const uint32_t sec_lo = use_tiles ? n_sp0 : 0u, sec_n = sort_bounced ? 0u : n_sp - sec_lo;
+        // Streams side by side, so that the thin end of one launch (few items left, most CUs idle) is filled by the others:
+        // the global map's groups on the caller's stream, the caustic map's groups on a second; each group kernel is followed,
+        // on its stream, by the per-query kernel for what it left.  A third stream carries the per-query gather of the bounced
+        // pixels' shade points for both maps when those are not grouped (PM_GROUP_BOUNCED=0).
         HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
         HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
         HIPCHK(hipStreamWaitEvent(ctx->aux2, ctx->ev_fork, 0));
-        const uint32_t *zero = &d_ctr->pad[0];   // "nothing left": the third stream's launches have only the bounced range
+        const uint32_t *zero = &d_ctr->pad;   // "nothing left": the third stream's launches have only the bounced range
         // the map whose build is already over goes first
         const bool global_late = gmap && gmap->pending && hipEventQuery(gmap->ready) != hipSuccess;
         for (int turn = 0; turn < 2; turn++) {
@@ -870,20 +909,22 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
             // map's gather): wait for it here
             PMCHK(map_ready(map));
             hipStream_t st = kind == 0 ? ctx->stream : ctx->aux;
-            uint32_t *lk = left + (size_t)kind * n_sp0, *nl = &d_ctr->n_left[kind];
+            uint32_t *lk = left + (size_t)kind * n_sp, *nl = &d_ctr->n_left[kind];
             float4 *strips = ctx->strips.as<float4>() + (size_t)kind * ctx->tile_blocks * TS_STRIDE;
             HIPCHK(hipEventRecord(ctx->ev_g[kind][0], st));
             if (kind == 0) {
                 if (use_tiles) {
-                    hipLaunchKernelGGL(k_gather<0>, dim3(ctx->query_blocks), block, 0, ctx->aux2, map->view, q, lk, zero, sec_lo, sec_n, sched + 4 * SCHED_WORDS);
-                    hipLaunchKernelGGL(k_gather_tile<0>, dim3(ctx->tile_blocks), dim3(64), 0, st, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sched, strips, dbg);
+                    if (sec_n) hipLaunchKernelGGL(k_gather<0>, dim3(ctx->query_blocks), block, 0, ctx->aux2, map->view, q, lk, zero, sec_lo, sec_n, sched + 4 * SCHED_WORDS);
+                    hipLaunchKernelGGL(k_gather_tile<0>, dim3(ctx->tile_blocks), dim3(64), 0, st, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sched, strips, dbg,
+                                       sorted, ctx->sp_groups.as<uint2>());
                 }
                 HIPCHK(hipEventRecord(ctx->ev_g[kind][1], st));
                 hipLaunchKernelGGL(k_gather<0>, dim3(ctx->query_blocks), block, 0, st, map->view, q, lk, nl, sec_lo, use_tiles ? 0u : sec_n, sched + SCHED_WORDS);
             } else {
                 if (use_tiles) {
-                    hipLaunchKernelGGL(k_gather<1>, dim3(ctx->query_blocks), block, 0, ctx->aux2, map->view, q, lk, zero, sec_lo, sec_n, sched + 5 * SCHED_WORDS);
-                    hipLaunchKernelGGL(k_gather_tile<1>, dim3(ctx->tile_blocks), dim3(64), 0, st, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sched + 2 * SCHED_WORDS, strips, dbg);
+                    if (sec_n) hipLaunchKernelGGL(k_gather<1>, dim3(ctx->query_blocks), block, 0, ctx->aux2, map->view, q, lk, zero, sec_lo, sec_n, sched + 5 * SCHED_WORDS);
+                    hipLaunchKernelGGL(k_gather_tile<1>, dim3(ctx->tile_blocks), dim3(64), 0, st, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sched + 2 * SCHED_WORDS, strips, dbg,
+                                       sorted, ctx->sp_groups.as<uint2>());
                 }
                 HIPCHK(hipEventRecord(ctx->ev_g[kind][1], st));
                 hipLaunchKernelGGL(k_gather<1>, dim3(ctx->query_blocks), block, 0, st, map->view, q, lk, nl, sec_lo, use_tiles ? 0u : sec_n, sched + 3 * SCHED_WORDS);
@@ -918,6 +959,7 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
         if (hipMemcpy(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost) == hipSuccess)
             fprintf(stderr, "[pm] shade points %u (primary %u), groups %u, left to the per-query gather: global %u caustic %u\n", hc.n_sp, n_sp0,
                     hc.n_groups, hc.n_left[0], hc.n_left[1]);
+        fprintf(stderr, "[pm] bounced pixels' shade points in spatial order: %u, in %u groups\n", n_sorted, hc.n_sgroups);
         fprintf(stderr, "[pm] lanes handed over, by reason (few photons, spread, radius, |S|, no lane served, -, own shortfall): %u %u %u %u %u %u %u\n", hc.why[1], hc.why[2],
                 hc.why[3], hc.why[4], hc.why[5], hc.why[6], hc.why[7]);
         for (int k = 0; k < 2; k++) {

@@ -26,7 +26,7 @@ struct FrameParams {
     int rank, world;
 };
 
-struct Counters { uint32_t n_sp, n_complex, n_secondary, n_groups, n_left[2], pad[2]; uint32_t why[8]; unsigned long long tphase[8]; uint32_t ghist[2][32]; };   // n_left[k]: shade points left to the per-query gather of map k
+struct Counters { uint32_t n_sp, n_complex, n_secondary, n_groups, n_left[2], pad, n_sgroups; uint32_t why[8]; unsigned long long tphase[8]; uint32_t ghist[2][32]; };   // n_left[k]: shade points left to the per-query gather of map k
 
 // shade point queue (SoA)
 struct SPQueue {
@@ -264,6 +264,67 @@ __global__ __launch_bounds__(256) void k_shadow(SceneView gs, FrameParams fp, SP
     q.direct[s] = direct;
 }
 
+// ---- spatial order for the shade points of bounced pixels.  They come out of k_secondary in pixel order of the bounce
+// trees, which says nothing about where they lie; sorted along a Morton curve over their own bounds, every 64 consecutive
+// ones are neighbours on some surface and are gathered as a group like the shade points of a pixel tile.
+__device__ inline uint32_t sp_f2ord(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ inline float sp_ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
+__global__ __launch_bounds__(256) void k_sp_bounds(SPQueue q, uint32_t lo, uint32_t n, uint32_t *bounds) {
+    __shared__ uint32_t part[4][6];
+    uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0, 0, 0};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        for (int a = 0; a < 3; a++) {
+            uint32_t v = sp_f2ord((float)q.geo[a * (size_t)q.cap + lo + i]);
+            mn[a] = min(mn[a], v); mx[a] = max(mx[a], v);
+        }
+    for (int a = 0; a < 3; a++) {
+        for (int s = 1; s < 64; s <<= 1) { mn[a] = min(mn[a], (uint32_t)__shfl_xor((int)mn[a], s)); mx[a] = max(mx[a], (uint32_t)__shfl_xor((int)mx[a], s)); }
+        if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][a] = mn[a]; part[threadIdx.x >> 6][3 + a] = mx[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        uint32_t v = part[0][threadIdx.x];
+        for (int w = 1; w < 4; w++) v = threadIdx.x < 3 ? min(v, part[w][threadIdx.x]) : max(v, part[w][threadIdx.x]);
+        if (threadIdx.x < 3) atomicMin(&bounds[threadIdx.x], v); else atomicMax(&bounds[threadIdx.x], v);
+    }
+}
+__global__ __launch_bounds__(256) void k_sp_morton(SPQueue q, uint32_t lo, uint32_t n, const uint32_t *bounds, uint64_t *keys, uint32_t *vals) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float ext = 0.f;
+    for (int a = 0; a < 3; a++) ext = fmaxf(ext, sp_ord2f(bounds[3 + a]) - sp_ord2f(bounds[a]));
+    uint32_t qv[3];
+    for (int a = 0; a < 3; a++) qv[a] = quant21((float)q.geo[a * (size_t)q.cap + lo + i], sp_ord2f(bounds[a]), ext);
+    keys[i] = morton63(qv[0], qv[1], qv[2]);
+    vals[i] = lo + i;
+}
+
+// Groups of the sorted shade points: the runs that share an octree cell of about `cell_rel` times the extent of their
+// bounds (a few 63-NN radii), cut into pieces of at most 64.  One thread per run (the thread of its first point; the end
+// of the run by binary search).  A run too short to pay for a shared candidate set goes straight to both maps' lists for
+// the per-query kernel.
+__global__ __launch_bounds__(256) void k_sp_groups(const uint64_t *keys, const uint32_t *sorted, uint32_t n, double cell_rel, uint32_t min_run, uint2 *sgroups,
+                                                    Counters *ctr, uint32_t *left0, uint32_t *left1) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int level = 1;
+    while (level < 10 && 1.0 / (double)(1 << (level + 1)) >= cell_rel) level++;
+    const int shift = 63 - 3 * level;
+    const uint64_t cell = keys[i] >> shift;
+    if (i > 0 && (keys[i - 1] >> shift) == cell) return;
+    uint32_t lo = i + 1, hi = n;                      // first index beyond the run
+    while (lo < hi) { uint32_t mid = lo + (hi - lo) / 2; if ((keys[mid] >> shift) == cell) lo = mid + 1; else hi = mid; }
+    const uint32_t cnt = lo - i;
+    if (cnt < min_run) {
+        uint32_t b0 = atomicAdd(&ctr->n_left[0], cnt), b1 = atomicAdd(&ctr->n_left[1], cnt);
+        for (uint32_t j = 0; j < cnt; j++) { left0[b0 + j] = sorted[i + j]; left1[b1 + j] = sorted[i + j]; }
+        return;
+    }
+    const uint32_t pieces = (cnt + 63u) / 64u, per = (cnt + pieces - 1u) / pieces;
+    uint32_t g = atomicAdd(&ctr->n_sgroups, pieces);
+    for (uint32_t c = 0; c < cnt; c += per, g++) sgroups[g] = make_uint2(i + c, min(per, cnt - c));
+}
+
 // One draw from a work counter per wave.  Out of line on purpose: inlined into the scheduling loop, the
 // lane-0 branch was threaded into the loop's control flow and lanes 1..63 were sent round the loop on their own.
 __device__ __noinline__ uint32_t wave_draw(uint32_t *ctr) {
@@ -350,23 +411,32 @@ __global__ __launch_bounds__(256) void k_gather(MapView m_in, SPQueue q, const u
 // cannot be gathered as a group appends its slots to `left` for k_gather.
 template <int KIND>
 __global__ __launch_bounds__(64) void k_gather_tile(MapView m_in, SPQueue q, const uint2 *groups, const Counters *ctr, uint32_t *left, uint32_t *n_left,
-                                                    uint32_t *sched, float4 *strips, int dbg) {
+                                                    uint32_t *sched, float4 *strips, int dbg, const uint32_t *sorted, const uint2 *sgroups) {
     MapView m = m_in;
     load_grid(m);
     __shared__ TileBuf tb;
     const int lane = threadIdx.x;
     const Strip S(reinterpret_cast<float *>(strips + (size_t)blockIdx.x * TS_STRIDE));   // this wave's strip for the shared candidate set
     double *out = KIND == 0 ? q.rad_g : q.rad_c;
-    const uint32_t n_groups = ctr->n_groups;
+    // the groups of the pixel tiles, then the groups of `sorted` (shade points of bounced pixels in spatial order)
+    const uint32_t n_tiles = ctr->n_groups, n_groups = n_tiles + ctr->n_sgroups;
     WorkDraw wd;
     uint32_t i0, i1;
     while (wd.next(sched, n_groups, 1u, i0, i1)) {
 #ifdef PM_TILE_STAMPS
         const unsigned long long tg0 = __builtin_amdgcn_s_memtime();
 #endif
-        const uint2 g = groups[i0];
-        const bool active = (uint32_t)lane < g.y;
-        const uint32_t s = g.x + (active ? (uint32_t)lane : 0u);
+        bool active;
+        uint32_t s;
+        if (i0 < n_tiles) {
+            const uint2 g = groups[i0];
+            active = (uint32_t)lane < g.y;
+            s = g.x + (active ? (uint32_t)lane : 0u);
+        } else {
+            const uint2 g = sgroups[i0 - n_tiles];
+            active = (uint32_t)lane < g.y;
+            s = sorted[g.x + (active ? (uint32_t)lane : 0u)];
+        }
         const V3 p = {q.geo[0 * (size_t)q.cap + s], q.geo[1 * (size_t)q.cap + s], q.geo[2 * (size_t)q.cap + s]};
         const V3 nrm = {q.geo[3 * (size_t)q.cap + s], q.geo[4 * (size_t)q.cap + s], q.geo[5 * (size_t)q.cap + s]};
         // dead: the lane goes to the per-query kernel (its group is too spread out for one shared set, or the lane itself

@@ -2,12 +2,14 @@
 # rocprofv3 evidence for bench.py's numbers: kernel trace + stats, then PMC passes (one rocprofv3 run per counter set, as
 # MI355X_MICROARCH.md prescribes), all on the same command.  Writes gpurun_out/prof_<tag>/ ; copy what is to be kept
 # into profiles/.
+# usage: profile_bench.sh <tag> [extra bench.py arguments, e.g. --scene spheres10k]
 tag=${1:-r01}
+shift
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+CMD="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline $*"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o tr -- $CMD > $out/trace.log 2>&1 || { echo "trace run failed"; tail -5 $out/trace.log; exit 1; }
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
