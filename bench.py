@@ -88,6 +88,12 @@ def main():
     ap.add_argument("--dump-pane", default="", help="rank 0 writes the final pane (uint32 raw) to this file")
     args = ap.parse_args()
 
+    # stdout carries the one JSON line and nothing else: whatever libraries write to fd 1 meanwhile (RCCL prints a version
+    # banner there when the process group starts) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -186,7 +192,8 @@ def main():
             out["cpu_baseline"] = cb
         if args.dump_pane:
             frame.step()[1].cpu().numpy().tofile(args.dump_pane)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     frame.close()
     ctx.close()
     if use_dist:

@@ -69,6 +69,8 @@ struct pm_ctx {
     hipEvent_t ev_g[2][3] = {};          // per map: gather begins, group kernel done, per-query kernel done
     // scene
     int nprims = 0, stride = 0;
+    double yield[2] = {0.60, 0.36};   // stored photons per emission attempt (global, caustic): the reference scene's to begin with, then
+                                      // what the last map of this scene showed (sizes the one emission range a map is made from)
     int scene_mode = SCENE_LDS;   // SCENE_LDS: staged per block; SCENE_GLOBAL: read in place; SCENE_GRID: in place, through the sphere grid
     size_t scene_b = 0;
     DevBuf scene, sgrid;
@@ -293,6 +295,7 @@ extern "C" int pm_scene_upload(pm_ctx *ctx, const pm_prim *prims, int32_t n) {
     HIPCHK(hipMemcpyAsync(ctx->scene.p, host.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->nprims = n; ctx->stride = stride; ctx->scene_b = bytes;
+    ctx->yield[0] = 0.60; ctx->yield[1] = 0.36;
     ctx->scene_mode = bytes <= LDS_SCENE_MAX ? SCENE_LDS : SCENE_GLOBAL;
     unsigned char *d = ctx->scene.as<unsigned char>();
     ctx->gv = SceneView{};
@@ -480,10 +483,15 @@ static int map_ready(pm_map *map) {
     if (map->kind < 0) return PM_OK;   // built from records: nothing to check
     const uint64_t n = (uint64_t)map->n;
     uint64_t have = std::min<uint64_t>(*map->h_got, n);
+    if (map->next_attempt >= 4096) {
+        // what this scene really yields, less four standard deviations and a hundredth: the next map's range is sized by it
+        const double a = (double)map->next_attempt, p = (double)*map->h_got / a;
+        ctx->yield[map->kind] = std::max(1e-4, p - 4.0 * sqrt(p * (1.0 - p) / a) - 0.01 * p);
+    }
     if (have >= n) return PM_OK;
     // the one range fell short of n photons (a scene that stores far fewer photons per attempt than the reference's):
     // keep emitting, synchronously on the caller's stream, then build again
-    const double yield = map->kind == PM_MAP_GLOBAL ? 0.60 : 0.36;
+    const double yield = ctx->yield[map->kind];
     BuildSlot &sl = ctx->slot[2];
     sl.stream = ctx->stream;
     int empty_batches = 0;
@@ -567,7 +575,7 @@ extern "C" int pm_map_create(pm_ctx *ctx, int32_t map_kind, int64_t n, uint64_t 
     // use of the map waits (map_ready), so two maps are emitted and built side by side, beside the first passes of the
     // frame that needs them.  When the guess does not hold (it does for any scene close to the reference's) map_ready
     // emits more and builds again.
-    const double yield = map_kind == PM_MAP_GLOBAL ? 0.60 : 0.36;
+    const double yield = ctx->yield[map_kind];
     if (rc == PM_OK) rc = take_slot(ctx, map->slot);
     if (rc == PM_OK) {
         BuildSlot &sl = ctx->slot[map->slot];

@@ -24,8 +24,8 @@ def attempt_ranges(begin, total, world):
     return [(begin + r * per, per) for r in range(world)]
 
 
-def batch_attempts(want, kind, world):
-    return int(want / YIELD_EST[kind]) + 4096 * world
+def batch_attempts(want, kind, world, yields=YIELD_EST):
+    return int(want / yields[kind]) + 4096 * world
 
 
 def owned_row_blocks(height, rank, world):
@@ -33,7 +33,7 @@ def owned_row_blocks(height, rank, world):
     return list(range(rank, nblk, world))
 
 
-def emit_sharded(n, kind, world, rank, emit_fn, allgather_fn):
+def emit_sharded(n, kind, world, rank, emit_fn, allgather_fn, yields=YIELD_EST):
     """First ``n`` stored photons in global attempt order.
 
     emit_fn(begin, count) -> records of this rank's range in attempt order (array-like, rows = photons).
@@ -44,7 +44,7 @@ def emit_sharded(n, kind, world, rank, emit_fn, allgather_fn):
     empty_rounds = 0
     while have < n:
         want = n - have
-        ranges = attempt_ranges(next_attempt, batch_attempts(want, kind, world), world)
+        ranges = attempt_ranges(next_attempt, batch_attempts(want, kind, world, yields), world)
         mine = emit_fn(*ranges[rank])
         shards = allgather_fn(mine)
         got = 0
@@ -118,6 +118,7 @@ class GpuFrame:
         self.last_stats = None
         self._shard_bufs = {}       # kind -> (own shard, all shards), device byte tensors reused across frames
         self._fast_shards = dist is not None and hasattr(dist, "all_gather_into_tensor")
+        self._yields = None         # stored photons per attempt in THIS scene, probed once (every rank finds the same numbers)
 
     # --- photon maps: createPhotonMap / createCausticPhotonMap, src/Raytrace.cpp:314-316
     def _emit_fn(self, kind):
@@ -132,14 +133,29 @@ class GpuFrame:
     def _allgather(self, mine):
         return allgather_records(self.dist, mine, self.world)
 
+    PROBE_ATTEMPTS = 65536
+
+    def yields(self):
+        """Stored photons per emission attempt of the uploaded scene, from a short synchronous emission per map kind
+        (attempts 0 .. 65535, the same on every rank), less a twentieth: sizes the ranks' attempt ranges."""
+        if self._yields is None:
+            torch = self.torch
+            tmp = torch.empty((self.PROBE_ATTEMPTS, 8), dtype=torch.int32, device=self.dev)
+            self._yields = {}
+            for kind in (0, 1):
+                got = self.ctx.emit_range(kind, self.seed, self.light_color, 0, self.PROBE_ATTEMPTS, tmp.data_ptr(), self.PROBE_ATTEMPTS)
+                self._yields[kind] = max(0.95 * got / self.PROBE_ATTEMPTS, 1e-4)
+        return self._yields
+
     def _build_map_from_shards(self, kind):
         """The sharded build without a host wait: this rank's attempt range -> a shard (header + records) on the
         device, ONE all-gather of the shards, assembly + index build queued behind it.  The ranges are sized so that
         together they hold n photons with room to spare; if they do not after all, the first use of the map raises and
         ``render`` falls back to ``emit_sharded`` (rounds of ranges with the counts on the host)."""
         torch = self.torch
-        per = (batch_attempts(self.n, kind, self.world) + self.world - 1) // self.world
-        cap = int(per * (YIELD_EST[kind] + 0.10)) + 1024
+        y = self.yields()
+        per = (batch_attempts(self.n, kind, self.world, y) + self.world - 1) // self.world
+        cap = int(per * min(1.0, y[kind] / 0.95 + 0.10)) + 1024
         nbytes = 32 + 32 * cap
         bufs = self._shard_bufs.get(kind)
         if bufs is None or bufs[0].numel() != nbytes:
@@ -152,7 +168,7 @@ class GpuFrame:
 
     def _build_map_by_rounds(self, kind):
         torch = self.torch
-        chunks, _ = emit_sharded(self.n, kind, self.world, self.rank, self._emit_fn(kind), self._allgather)
+        chunks, _ = emit_sharded(self.n, kind, self.world, self.rank, self._emit_fn(kind), self._allgather, self.yields())
         rec = torch.cat(chunks) if len(chunks) != 1 else chunks[0].contiguous()
         return self.ctx.build_map(rec.data_ptr(), kind, n=self.n, on_device=True)
 
