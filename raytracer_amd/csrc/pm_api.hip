@@ -311,18 +311,30 @@ extern "C" int pm_scene_upload(pm_ctx *ctx, const pm_prim *prims, int32_t n) {
         HostSceneGrid hg;
         build_scene_grid(prims, n, hg);
         size_t b_loose = (hg.loose.size() * sizeof(int) + 255) & ~(size_t)255, b_start = (hg.cell_start.size() * sizeof(uint32_t) + 255) & ~(size_t)255;
-        size_t b_refs = hg.refs.size() * sizeof(int);
-        PMCHK(ctx->sgrid.ensure(b_loose + b_start + b_refs + 256));
+        size_t b_refs = (hg.refs.size() * sizeof(int) + 255) & ~(size_t)255, b_packed = hg.refs.size() * 8 * sizeof(double);
+        std::vector<double> packed(hg.refs.size() * 8);
+        for (size_t r = 0; r < hg.refs.size(); r++) {
+            const pm_prim &p = prims[hg.refs[r]];
+            double *P = &packed[r * 8];
+            P[0] = p.x; P[1] = p.y; P[2] = p.z; P[3] = p.radius; P[4] = p.dx; P[5] = p.dy; P[6] = p.dz;
+            long long id = hg.refs[r];
+            memcpy(&P[7], &id, 8);
+        }
+        PMCHK(ctx->sgrid.ensure(b_loose + b_start + b_refs + b_packed + 256));
         unsigned char *gd = ctx->sgrid.as<unsigned char>();
         if (!hg.loose.empty()) HIPCHK(hipMemcpyAsync(gd, hg.loose.data(), hg.loose.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(gd + b_loose, hg.cell_start.data(), hg.cell_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        if (!hg.refs.empty()) HIPCHK(hipMemcpyAsync(gd + b_loose + b_start, hg.refs.data(), b_refs, hipMemcpyHostToDevice, ctx->stream));
+        if (!hg.refs.empty()) {
+            HIPCHK(hipMemcpyAsync(gd + b_loose + b_start, hg.refs.data(), hg.refs.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipMemcpyAsync(gd + b_loose + b_start + b_refs, packed.data(), b_packed, hipMemcpyHostToDevice, ctx->stream));
+        }
         HIPCHK(hipStreamSynchronize(ctx->stream));
         SceneGrid &G = ctx->gv.grid;
         G.nloose = (int)hg.loose.size(); G.rx = hg.res[0]; G.ry = hg.res[1]; G.rz = hg.res[2];
         G.loose = reinterpret_cast<const int *>(gd);
         G.cell_start = reinterpret_cast<const uint32_t *>(gd + b_loose);
         G.refs = reinterpret_cast<const int *>(gd + b_loose + b_start);
+        G.packed = reinterpret_cast<const double *>(gd + b_loose + b_start + b_refs);
         for (int a = 0; a < 3; a++) { G.lo[a] = hg.lo[a]; G.hi[a] = hg.hi[a]; G.cs[a] = hg.cs[a]; G.inv_cs[a] = 1.0 / hg.cs[a]; }
         ctx->scene_mode = SCENE_GRID;
         if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] scene grid %d x %d x %d, %zu refs for %d spheres, %zu loose primitives\n", G.rx, G.ry, G.rz,

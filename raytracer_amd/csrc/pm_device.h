@@ -86,6 +86,8 @@ struct SceneGrid {
     const int *loose;            // ascending primitive ids
     const uint32_t *cell_start;  // [rx*ry*rz + 1] into refs
     const int *refs;             // sphere ids of every cell whose padded box (swept over dt in [0,1]) touches the cell
+    const double *packed;        // [refs][8]: x y z radius dx dy dz of the sphere of each ref, and its id (as an integer in the
+                                 // last slot): one 64-byte line per test instead of seven lines of the field arrays
     double lo[3], hi[3], cs[3], inv_cs[3];
 };
 enum { SCENE_LDS = 0, SCENE_GLOBAL = 1, SCENE_GRID = 2 };   // how a kernel reads the scene
@@ -116,6 +118,24 @@ __device__ inline bool sphere_hit(const SceneView &s, int i, const V3 &o, const 
     if (b < 0) return false;
     double d2 = (lx * lx + ly * ly + lz * lz) - b * b;
     double radius = s.f(G_RADIUS, i);
+    if (d2 > radius * radius) return false;
+    double t = sqrt(radius * radius - d2);
+    if (t < 0) t = b + t; else t = b - t;
+    if (t < 0) return false;
+    res.x = d.x * t + o.x; res.y = d.y * t + o.y; res.z = d.z * t + o.z;
+    return true;
+}
+// the same test on a packed record (SceneGrid::packed): same operands, same operations
+__device__ inline bool sphere_hit_packed(const double *P, const V3 &o, const V3 &d, double dt, V3 &res) {
+    const double4 a = *reinterpret_cast<const double4 *>(P), b4 = *reinterpret_cast<const double4 *>(P + 4);   // x y z radius | dx dy dz id
+    double x0 = a.x + dt * b4.x;
+    double y0 = a.y + dt * b4.y;
+    double z0 = a.z + dt * b4.z;
+    double lx = x0 - o.x, ly = y0 - o.y, lz = z0 - o.z;
+    double b = d.x * lx + d.y * ly + d.z * lz;
+    if (b < 0) return false;
+    double d2 = (lx * lx + ly * ly + lz * lz) - b * b;
+    double radius = a.w;
     if (d2 > radius * radius) return false;
     double t = sqrt(radius * radius - d2);
     if (t < 0) t = b + t; else t = b - t;
@@ -277,7 +297,17 @@ __device__ inline int scene_intersect(const SceneView &s, const V3 &src, const V
         // every hit from here on lies at parameter >= t_in: squared distance >= t_in^2 |dir|^2 (margin for rounding)
         double far = t_in * (1.0 - 1e-9) - 1e-9;
         if (far > 0 && far * far * dd > nearest) return false;
-        for (uint32_t r = b; r < e; r++) candidate(G.refs[r]);
+        for (uint32_t r = b; r < e; r++) {
+            const double *P = G.packed + (size_t)r * 8;
+            const int i = (int)__double_as_longlong(P[7]);
+            if (i == exclude) continue;
+            if (sphere_hit_packed(P, src, dir, dt, res)) {
+                double dist = (res.x - src.x) * (res.x - src.x);
+                dist += (res.y - src.y) * (res.y - src.y);
+                dist += (res.z - src.z) * (res.z - src.z);
+                if (dist < nearest || (dist == nearest && i < nearest_obj)) { nearest = dist; nearest_obj = i; fres = res; }
+            }
+        }
         return true;
     });
     if (nearest_obj >= 0) prim_normal(s, nearest_obj, dt, fres, fnrm);
@@ -307,7 +337,13 @@ __device__ inline bool shadow_blocked(const SceneView &s, const V3 &p, const V3 
     grid_walk(G, p, ray, [&](uint32_t b, uint32_t e, double t_in) {
         double far = t_in * (1.0 - 1e-9) - 1e-9;
         if (far > 0 && far * far * dd > max_dist) return false;
-        for (uint32_t r = b; r < e; r++) if (blocks(G.refs[r])) { hit = true; return false; }
+        for (uint32_t r = b; r < e; r++) {
+            const double *P = G.packed + (size_t)r * 8;
+            if ((int)__double_as_longlong(P[7]) == obj) continue;
+            if (!sphere_hit_packed(P, p, ray, dt, result)) continue;
+            double ds = (p.x - result.x) * (p.x - result.x) + (p.y - result.y) * (p.y - result.y) + (p.z - result.z) * (p.z - result.z);
+            if (!(ds > max_dist)) { hit = true; return false; }
+        }
         return true;
     });
     return hit;
