@@ -451,7 +451,7 @@ static int build_index(pm_map *map, BuildSlot &sl) {
     for (; l > 4; l--)
         hipLaunchKernelGGL(k_cell_boxes_up, dim3((unsigned)(((1LL << (3 * l)) + 255) / 256)), dim3(256), 0, sl.stream, map->cells.as<uint32_t>(), l,
                            map->cbox.as<uint64_t>());
-    if (l >= 0) hipLaunchKernelGGL(k_cell_boxes_top, dim3(1), dim3(1024), 0, sl.stream, map->cells.as<uint32_t>(), l, map->cbox.as<uint64_t>());
+    if (l >= 0) hipLaunchKernelGGL(k_cell_boxes_top, dim3(1), dim3(256), 0, sl.stream, map->cells.as<uint32_t>(), l, map->cbox.as<uint64_t>());
     PMCHK(map->grid.ensure(sizeof(GridParams)));
     hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(64), 0, sl.stream, sl.bounds.as<uint32_t>(), map->grid.as<GridParams>());
     v.grid = map->grid.as<GridParams>();   // (glo / gext / gu stay zero on the host: kernels load them from here)

@@ -236,26 +236,24 @@ __device__ inline void grid_walk(const SceneGrid &G, const V3 &o, const V3 &d, F
     int ix = grid_enter(G.lo[0], G.cs[0], G.inv_cs[0], G.rx, o.x, d.x, invx, t0, tx);
     int iy = grid_enter(G.lo[1], G.cs[1], G.inv_cs[1], G.ry, o.y, d.y, invy, t0, ty);
     int iz = grid_enter(G.lo[2], G.cs[2], G.inv_cs[2], G.rz, o.z, d.z, invz, t0, tz);
+    // One step = one axis advanced by one cell; branch-free, so lanes stepping along different axes stay together.  The
+    // crossing parameters are advanced by a constant per axis (rounding drifts by a few ulp per step, far inside the
+    // padding of the sphere boxes).
     const int sx = d.x > 0 ? 1 : -1, sy = d.y > 0 ? 1 : -1, sz = d.z > 0 ? 1 : -1;
+    const double dtx = G.cs[0] * fabs(invx), dty = G.cs[1] * fabs(invy), dtz = G.cs[2] * fabs(invz);
+    const int cx = sx, cy = sy * G.rx, cz = sz * G.rx * G.ry;
+    int c = (iz * G.ry + iy) * G.rx + ix;
     double t_in = t0;
     for (int guard = G.rx + G.ry + G.rz + 3; guard > 0; guard--) {
-        uint32_t c = ((uint32_t)iz * (uint32_t)G.ry + (uint32_t)iy) * (uint32_t)G.rx + (uint32_t)ix;
         uint32_t b = G.cell_start[c], e = G.cell_start[c + 1];
         if (!visit(b, e, t_in)) return;
-        if (tx <= ty && tx <= tz) {
-            t_in = tx; ix += sx;
-            if (ix < 0 || ix >= G.rx) return;
-            tx = (G.lo[0] + (double)(ix + (sx > 0 ? 1 : 0)) * G.cs[0] - o.x) * invx;
-        } else if (ty <= tz) {
-            t_in = ty; iy += sy;
-            if (iy < 0 || iy >= G.ry) return;
-            ty = (G.lo[1] + (double)(iy + (sy > 0 ? 1 : 0)) * G.cs[1] - o.y) * invy;
-        } else {
-            t_in = tz; iz += sz;
-            if (iz < 0 || iz >= G.rz) return;
-            tz = (G.lo[2] + (double)(iz + (sz > 0 ? 1 : 0)) * G.cs[2] - o.z) * invz;
-        }
+        const bool bx = tx <= ty && tx <= tz, by = !bx && ty <= tz, bz = !bx && !by;
+        t_in = bx ? tx : (by ? ty : tz);
         if (!(t_in <= t1)) return;
+        ix += bx ? sx : 0; iy += by ? sy : 0; iz += bz ? sz : 0;
+        tx += bx ? dtx : 0.0; ty += by ? dty : 0.0; tz += bz ? dtz : 0.0;
+        c += bx ? cx : (by ? cy : cz);
+        if ((unsigned)ix >= (unsigned)G.rx || (unsigned)iy >= (unsigned)G.ry || (unsigned)iz >= (unsigned)G.rz) return;
     }
 }
 
@@ -292,11 +290,13 @@ __device__ inline int scene_intersect(const SceneView &s, const V3 &src, const V
     };
     const SceneGrid &G = s.grid;
     for (int k = 0; k < G.nloose; k++) candidate(G.loose[k]);
-    double dd = dir.x * dir.x + dir.y * dir.y + dir.z * dir.z;    // 1 within rounding; kept for rays that are not
+    const double dd = dir.x * dir.x + dir.y * dir.y + dir.z * dir.z;    // 1 within rounding; kept for rays that are not
+    // every hit in a cell entered at parameter t lies at squared distance >= t^2 |dir|^2: beyond t_stop nothing can beat
+    // `nearest` (margin for the rounding of both sides)
+    auto stop_at = [&](double lim) { return sqrt(lim / dd) * (1.0 + 1e-9) + 1e-9; };
+    double t_stop = stop_at(nearest);
     grid_walk(G, src, dir, [&](uint32_t b, uint32_t e, double t_in) {
-        // every hit from here on lies at parameter >= t_in: squared distance >= t_in^2 |dir|^2 (margin for rounding)
-        double far = t_in * (1.0 - 1e-9) - 1e-9;
-        if (far > 0 && far * far * dd > nearest) return false;
+        if (t_in > t_stop) return false;
         for (uint32_t r = b; r < e; r++) {
             const double *P = G.packed + (size_t)r * 8;
             const int i = (int)__double_as_longlong(P[7]);
@@ -305,7 +305,7 @@ __device__ inline int scene_intersect(const SceneView &s, const V3 &src, const V
                 double dist = (res.x - src.x) * (res.x - src.x);
                 dist += (res.y - src.y) * (res.y - src.y);
                 dist += (res.z - src.z) * (res.z - src.z);
-                if (dist < nearest || (dist == nearest && i < nearest_obj)) { nearest = dist; nearest_obj = i; fres = res; }
+                if (dist < nearest || (dist == nearest && i < nearest_obj)) { nearest = dist; nearest_obj = i; fres = res; t_stop = stop_at(nearest); }
             }
         }
         return true;
@@ -332,11 +332,11 @@ __device__ inline bool shadow_blocked(const SceneView &s, const V3 &p, const V3 
     }
     const SceneGrid &G = s.grid;
     for (int k = 0; k < G.nloose; k++) if (blocks(G.loose[k])) return true;
-    double dd = ray.x * ray.x + ray.y * ray.y + ray.z * ray.z;
+    const double dd = ray.x * ray.x + ray.y * ray.y + ray.z * ray.z;
+    const double t_stop = sqrt(max_dist / dd) * (1.0 + 1e-9) + 1e-9;    // hits in cells entered later are beyond max_dist
     bool hit = false;
     grid_walk(G, p, ray, [&](uint32_t b, uint32_t e, double t_in) {
-        double far = t_in * (1.0 - 1e-9) - 1e-9;
-        if (far > 0 && far * far * dd > max_dist) return false;
+        if (t_in > t_stop) return false;
         for (uint32_t r = b; r < e; r++) {
             const double *P = G.packed + (size_t)r * 8;
             if ((int)__double_as_longlong(P[7]) == obj) continue;
