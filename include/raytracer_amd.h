@@ -98,7 +98,9 @@ int pm_ctx_destroy(pm_ctx *ctx);
 int pm_ctx_set_stream(pm_ctx *ctx, void *hip_stream);
 const char *pm_last_error(void);
 
-/* Scene + SceneObject*[] (src/Scene.h:24-34): flattened copy, index = object id. */
+/* Scene + SceneObject*[] (src/Scene.h:24-34): flattened copy, index = object id.  With 64 spheres or more the library
+ * also builds a uniform grid over the spheres (host side, here): Scene::intersect's linear scan (src/Scene.cpp:25-47)
+ * then tests only the primitives along the ray and returns the very hit the scan would (PM_SCENE_GRID=0: never). */
 int pm_scene_upload(pm_ctx *ctx, const pm_prim *prims, int32_t n);
 
 /* The outer while-loop body of createPhotonMap / createCausticPhotonMap (src/PhotonMap.cpp:288-367,
@@ -123,11 +125,16 @@ int pm_emit_shard(pm_ctx *ctx, int32_t map_kind, uint64_t seed, const double lig
 int pm_map_build_shards(pm_ctx *ctx, const void *d_shards, int32_t world, uint64_t shard_stride, int64_t n, pm_map **out);
 
 /* createKDTree (src/PhotonMap.cpp:64-140): builds the spatial index (linear octree over
- * Morton-sorted photons) from n records in emission order.  records_on_device: 0 = host pointer, 1 = device. */
+ * Morton-sorted photons) from n records in emission order.  records_on_device: 0 = host pointer, 1 = device.
+ * The records are copied in stream order (the caller may reuse them behind the call); the build is left on one of the
+ * context's build streams and the first use of the map waits for it. */
 int pm_map_build(pm_ctx *ctx, const pm_photon *records, int64_t n, int32_t records_on_device, pm_map **out);
 
 /* createPhotonMap / createCausticPhotonMap (src/PhotonMap.h:28-29): the first n successful attempts,
- * in attempt order from attempt 0, then pm_map_build.  *attempts_used may be NULL. */
+ * in attempt order from attempt 0, then pm_map_build.  With attempts_used == NULL the call returns at once: emission
+ * and build run on one of the context's two build streams (two maps side by side, beside the first passes of the frame
+ * that needs them) and the first use of the map waits.  Otherwise the call waits and *attempts_used receives the
+ * attempts issued. */
 int pm_map_create(pm_ctx *ctx, int32_t map_kind, int64_t n, uint64_t seed, const double light_color[3],
                   pm_map **out, uint64_t *attempts_used);
 int pm_map_size(const pm_map *map, int64_t *n);
