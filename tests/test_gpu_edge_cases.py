@@ -1,0 +1,88 @@
+"""GPU edge cases through the C-ABI: ragged frame sizes, empty and tiny photon maps, the PM_FLAG_* switches, and the
+error channel (the reference has none: every misuse there is undefined behaviour; here it is a status + message)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pane_pair(gpu_ctx, orc, w, h, n, seed, flags=0):
+    import raytracer_amd as ra
+    g, c = gpu_ctx.create_map(0, n, seed), gpu_ctx.create_map(1, n, seed)
+    rp = gpu_ctx.params(w, h, seed, flags=flags)
+    pane, st = gpu_ctx.render(None if flags & ra.PM_FLAG_NO_GLOBAL else g, None if flags & ra.PM_FLAG_NO_CAUSTIC else c, rp)
+    og, oc = orc.Map(g.download()), orc.Map(c.download())
+    want, ost = orc.render(orc.default_scene(), og, oc, orc.params(w, h, seed, flags=flags), nthreads=8)
+    g.destroy(); c.destroy(); og.close(); oc.close()
+    return pane, want, st, ost
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (37, 23), (640, 1), (17, 200), (333, 129)])
+def test_ragged_frame_sizes(gpu_ctx, orc, w, h):
+    """Widths and heights that fill neither a 16 x 16 pixel block nor a 16-row block."""
+    pane, want, st, ost = _pane_pair(gpu_ctx, orc, w, h, 3000, 19)
+    assert pane.shape == (h, w) and np.array_equal(pane, want)
+    assert (st.closest_hit_queries, st.shadow_queries, st.gathers) == (ost.closest_hit_queries, ost.shadow_queries, ost.gathers)
+
+
+@pytest.mark.parametrize("n", [0, 1, 62, 63])
+def test_empty_and_tiny_maps(gpu_ctx, orc, n):
+    """Fewer photons than the estimate asks for (k = 63): find_nearest_photons returns what there is."""
+    pane, want, _, _ = _pane_pair(gpu_ctx, orc, 160, 100, n, 3)
+    assert np.array_equal(pane, want)
+    m = gpu_ctx.create_map(0, n, 3)
+    assert len(m) == n and len(m.download()) == n
+    found, idx, d2 = gpu_ctx.knn_query(m, [[0.0, -4.9, 5.0], [100.0, 100.0, 100.0]])
+    om = orc.Map(m.download())
+    f0, _, od2 = om.knn_exact([0.0, -4.9, 5.0])
+    assert found[0] == f0 and found[1] == 0          # nothing within max_dist of the far point
+    assert np.array_equal(np.sort(d2[0][:f0]), np.sort(np.asarray(od2)[:f0]))
+    om.close(); m.destroy()
+
+
+@pytest.mark.parametrize("flags", [1, 2, 4, 3, 7])
+def test_flags(gpu_ctx, orc, flags):
+    pane, want, _, _ = _pane_pair(gpu_ctx, orc, 200, 120, 5000, 11, flags=flags)
+    assert np.array_equal(pane, want)
+
+
+def test_row_split_of_a_ragged_frame(gpu_ctx):
+    """world = 3 over 5 row blocks (the last one 7 rows): the three ranks' rows make up the single-rank pane."""
+    w, h, n, seed = 123, 71, 4000, 5
+    g, c = gpu_ctx.create_map(0, n, seed), gpu_ctx.create_map(1, n, seed)
+    whole, _ = gpu_ctx.render(g, c, gpu_ctx.params(w, h, seed))
+    parts = np.zeros((h, w), dtype=np.uint32)
+    for rank in range(3):
+        gpu_ctx.render(g, c, gpu_ctx.params(w, h, seed, rank=rank, world=3), pane=parts)
+    assert np.array_equal(parts, whole)
+    g.destroy(); c.destroy()
+
+
+def test_errors_are_reported_not_undefined():
+    import raytracer_amd as ra
+    ctx, other = ra.Context(0), ra.Context(0)
+    try:
+        with pytest.raises(ra.PMError, match="no scene"):
+            ctx.create_map(0, 100, 1)
+        ctx.upload_scene(ra.default_scene()); other.upload_scene(ra.default_scene())
+        with pytest.raises(ra.PMError, match="kind"):
+            ctx.create_map(7, 100, 1)
+        bad = ra.default_scene(); bad[3]["kind"] = 9
+        with pytest.raises(ra.PMError, match="unknown kind"):
+            ctx.upload_scene(bad)
+        g, c = ctx.create_map(0, 100, 1), ctx.create_map(1, 100, 1)
+        with pytest.raises(ra.PMError, match="another context"):
+            other.render(g, c, other.params(32, 32, 1))
+        with pytest.raises(ra.PMError, match="missing"):
+            ctx.render(None, c, ctx.params(32, 32, 1))
+        rp = ctx.params(0, 32, 1)
+        with pytest.raises(ra.PMError):
+            ctx.render(g, c, rp)
+        with pytest.raises(ra.PMError):
+            ra.Context(99)
+        # the context still works after the errors
+        pane, _ = ctx.render(g, c, ctx.params(32, 32, 1))
+        assert pane.shape == (32, 32)
+        g.destroy(); c.destroy()
+    finally:
+        ctx.close(); other.close()
