@@ -86,3 +86,20 @@ def test_errors_are_reported_not_undefined():
         g.destroy(); c.destroy()
     finally:
         ctx.close(); other.close()
+
+
+@pytest.mark.parametrize("cam,lc", [((1.5, 0.75, -10.0), (0.6, 0.6, 0.6)), ((-2.0, -1.0, -14.0), (0.9, 0.5, 0.2)), ((0.0, 3.0, -6.0), (0.25, 0.25, 1.0))])
+def test_other_cameras_and_light_colours(gpu_ctx, orc, cam, lc):
+    """renderScene's camera and light colour are arguments here (src/Image.cpp:33, src/Raytrace.cpp:311): other values than
+    the reference's own, against the oracle."""
+    w, h, n, seed = 240, 150, 8000, 21
+    g, c = gpu_ctx.create_map(0, n, seed, lc), gpu_ctx.create_map(1, n, seed, lc)
+    for kind, m in ((0, g), (1, c)):
+        want, _ = orc.emit(orc.default_scene(), kind, seed, n, light_color=lc)
+        assert np.array_equal(m.download().view(np.uint8), np.asarray(want).view(np.uint8))
+    pane, st = gpu_ctx.render(g, c, gpu_ctx.params(w, h, seed, cam=cam, light_color=lc))
+    og, oc = orc.Map(g.download()), orc.Map(c.download())
+    want, ost = orc.render(orc.default_scene(), og, oc, orc.params(w, h, seed, cam=cam, light_color=lc), nthreads=8)
+    assert np.array_equal(pane, want)
+    assert (st.closest_hit_queries, st.shadow_queries, st.gathers) == (ost.closest_hit_queries, ost.shadow_queries, ost.gathers)
+    g.destroy(); c.destroy(); og.close(); oc.close()
