@@ -6,7 +6,10 @@
 //   k_secondary      one lane per bounced pixel: the traceRay recursion as an explicit-stack state
 //                    machine (shared mutable (src,ray) pair); emits further shade points
 //   k_shadow         one lane per shade point: 25 shadow any-hit rays + direct term
-//   k_gather<KIND>   one WAVE per shade point: exact 63-NN + radiance estimate (pm_knn.h)
+//   k_sp_*           the bounced pixels' shade points in Morton order, cut into groups by octree cell
+//   k_gather_tile<KIND>  one wave per GROUP of neighbouring shade points, one lane per query (pm_tile.h)
+//   k_gather<KIND>   one WAVE per shade point, for what the group kernel leaves: exact 63-NN + radiance estimate
+//                    (pm_grid.h, pm_knn.h)
 //   k_shade          one lane per shade point: clamp, colour, 8-bit pack; final pixel for simple pixels
 //   k_resolve        one lane per bounced pixel: folds its node table bottom-up into the final pixel
 #pragma once

@@ -1,20 +1,23 @@
 // pm_tile.h -- the radiance gather for a GROUP of up to 64 neighbouring shade points (the shade points of one
-// 8x8 pixel tile), one query per lane.  Same results, bit for bit, as one wave per query (pm_grid.h): the exact
-// 63rd-smallest squared distance of every query and the canonical order-independent radiance sum.
+// 8x8 pixel tile, or a run of bounced pixels' shade points that share an octree cell), one query per lane.  Same
+// results, bit for bit, as one wave per query (pm_grid.h): the exact 63rd-smallest squared distance of every query
+// and the canonical order-independent radiance sum.
 //
-// Neighbouring pixels on a wall search nearly the same photons, so the group shares the work that one wave per
+// Neighbouring points on a wall search nearly the same photons, so the group shares the work that one wave per
 // query repeats 64 times:
 //   1. one ordinary 63-NN query (pm_grid.h) at the centre c of the group's bounding box gives the scale r_c; the group
 //      shares the squared radius L = 1.6 r_c;
 //   2. one octree range walk collects S = every photon closer than sqrt(L) to the bounding box (a few hundred
-//      photons) into LDS: S holds every photon closer than sqrt(L) to any of the group's points;
-//   3. every lane finds ITS exact 63rd distance in S: a 32-bin histogram of d2 over [0, L) (pass 1); a lane that counts
-//      63 or more has its whole answer inside S; the photons of the bin in which the running count crosses 63 are listed
-//      and ranked exactly (pass 2); photons of lower bins, and of that bin below r_q, form the lane's member list;
+//      photons: every photon closer than sqrt(L) to any of the group's points) into the wave's strip of device
+//      memory, as float positions relative to the box centre + photon indices;
+//   3. every lane finds ITS exact 63rd distance in S in two passes over S (staged through LDS in chunks, packed FP32):
+//      a 64-bin histogram of d2 over [0, L) brackets it (pass 1); the photons surely below the bracket are listed as
+//      the lane's members and the few photons inside it are ranked by their exact double d2 (pass 2 + ranking), which
+//      gives the exact r_q and the remaining members;
 //   4. every lane sums the radiance terms of its own members in 64-bit fixed point.
 // A lane with fewer than 63 photons inside the shared radius, or a whole group that is not coherent (points on different
-// surfaces, far from every photon, |S| over the LDS budget), is handed to the one-wave-per-query kernel through a list of
-// shade point slots.
+// surfaces, far from every photon, |S| over the strip's capacity), is handed to the one-wave-per-query kernel through a
+// list of shade point slots.
 #pragma once
 #include "pm_grid.h"
 
