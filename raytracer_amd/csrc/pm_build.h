@@ -1,5 +1,5 @@
-// pm_build.h -- photon emission (one attempt per lane, ordered compaction) and the GPU build
-// of the 64-ary BVH over Hilbert-sorted photons.
+// pm_build.h -- photon emission (one attempt per lane, ordered compaction), the assembly of a map from the ranks'
+// shards, and the GPU build of the photon index: Morton keys, the linear octree's cell tables and tight cell boxes.
 #pragma once
 #include "pm_device.h"
 #include "pm_knn.h"
