@@ -77,10 +77,11 @@ struct pm_ctx {
     SceneView gv{};
     // frame work buffers (grow only, reused across frames)
     DevBuf geo, obj, pixel, node, tabslot, direct, radg, radc, color, clist, tab, ctr, pane, sched, groups, left, strips;
-    DevBuf sp_keys_in, sp_keys_out, sp_vals_in, sp_vals_out, sp_sort_tmp, sp_bounds, sp_groups;   // spatial order of the bounced pixels' shade points
+    DevBuf sp_keys_in, sp_keys_out, sp_vals_in, sp_vals_out, sp_sort_tmp, sp_bounds, sp_groups, sp_early, sp_pieces;   // spatial order of the bounced pixels' shade points
     bool use_tiles = true;     // PM_GATHER_TILE=0: every shade point goes through the per-query kernel (A/B switch)
     double sp_cell = 6.0;      // cell size of those groups in 63-NN radii (PM_SP_CELL), and the shortest run worth a group (PM_SP_MIN_RUN)
     int sp_min_run = 16;
+    double sp_est = 1.0;       // a piece is grouped when its expected candidate set is within this many times PM_TILE_EST_MAX (PM_SP_EST)
     bool group_bounced = true; // PM_GROUP_BOUNCED=0: the bounced pixels' shade points stay with the per-query kernel (A/B switch)
     int tile_blocks = 0, query_blocks = 0;   // resident blocks of the two gather kernels on this device
     uint32_t sp_cap = 0;
@@ -153,7 +154,7 @@ extern "C" int pm_ctx_destroy(pm_ctx *ctx) {
     if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
     DevBuf *bufs[] = {&ctx->scene, &ctx->sgrid, &ctx->geo, &ctx->obj, &ctx->pixel, &ctx->node, &ctx->tabslot, &ctx->direct, &ctx->radg, &ctx->radc,
                       &ctx->color, &ctx->clist, &ctx->tab, &ctx->ctr, &ctx->pane, &ctx->sched, &ctx->groups, &ctx->left, &ctx->strips,
-                      &ctx->sp_keys_in, &ctx->sp_keys_out, &ctx->sp_vals_in, &ctx->sp_vals_out, &ctx->sp_sort_tmp, &ctx->sp_bounds, &ctx->sp_groups};
+                      &ctx->sp_keys_in, &ctx->sp_keys_out, &ctx->sp_vals_in, &ctx->sp_vals_out, &ctx->sp_sort_tmp, &ctx->sp_bounds, &ctx->sp_groups, &ctx->sp_early, &ctx->sp_pieces};
     for (DevBuf *b : bufs) b->release();
     for (pm_map *m : ctx->spare) free_map(m);
     ctx->spare.clear();
@@ -800,6 +801,7 @@ static int gather_blocks(pm_ctx *ctx) {
     const char *eb = getenv("PM_GROUP_BOUNCED");
     ctx->group_bounced = !(eb && eb[0] == '0');
     if (const char *v = getenv("PM_SP_CELL")) { double x = atof(v); if (x > 0.1 && x < 100) ctx->sp_cell = x; }
+    if (const char *v = getenv("PM_SP_EST")) { double x = atof(v); if (x > 0.01 && x < 1000) ctx->sp_est = x; }
     if (const char *v = getenv("PM_SP_MIN_RUN")) { int x = atoi(v); if (x >= 1 && x <= 64) ctx->sp_min_run = x; }
     if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] resident gather blocks: group kernel %d (%d per CU), per-query kernel %d (%d per CU), %d CUs\n", ctx->tile_blocks, per_cu_t,
                                     ctx->query_blocks, per_cu_q, cus);
@@ -903,8 +905,13 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
             long long n_ph = std::max<long long>(1, std::min(gmap ? gmap->n : (1LL << 40), cmap ? cmap->n : (1LL << 40)));
             double cell_rel = ctx->sp_cell * sqrt(63.0 * 6.0 / (3.14159265 * (double)n_ph));
             PMCHK(ctx->sp_groups.ensure((size_t)n_sorted * sizeof(uint2)));
-            hipLaunchKernelGGL(k_sp_groups, dim3((n_sorted + 255) / 256), block, 0, ctx->stream, ctx->sp_keys_out.as<uint64_t>(), ctx->sp_vals_out.as<uint32_t>(), n_sorted,
-                               cell_rel, (uint32_t)ctx->sp_min_run, ctx->sp_groups.as<uint2>(), d_ctr, left, left + n_sp);
+            PMCHK(ctx->sp_early.ensure((size_t)n_sorted * 4));
+            PMCHK(ctx->sp_pieces.ensure((size_t)n_sorted * sizeof(uint2)));
+            hipLaunchKernelGGL(k_sp_pieces, dim3((n_sorted + 255) / 256), block, 0, ctx->stream, ctx->sp_keys_out.as<uint64_t>(), n_sorted, cell_rel, ctx->sp_pieces.as<uint2>(), d_ctr);
+            // one wave per piece; at most one piece per min(64, run) points, launched for the worst case of one piece per point
+            hipLaunchKernelGGL(k_sp_classify, dim3((n_sorted + 3) / 4), block, 0, ctx->stream, q, ctx->sp_vals_out.as<uint32_t>(), ctx->sp_pieces.as<uint2>(),
+                               ctx->sp_bounds.as<uint32_t>(), (double)n_ph / 6.0, ctx->sp_est * (double)PM_TILE_EST_MAX, (uint32_t)ctx->sp_min_run,
+                               ctx->sp_groups.as<uint2>(), d_ctr, ctx->sp_early.as<uint32_t>());
         }
         const uint32_t *sorted = ctx->sp_vals_out.as<uint32_t>();
         n_primary_sp = use_tiles ? n_sp0 + n_sorted : 0u;
@@ -935,6 +942,7 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
             if (kind == 0) {
                 if (use_tiles) {
                     if (sec_n) hipLaunchKernelGGL(k_gather<0>, dim3(ctx->query_blocks), block, 0, ctx->aux2, map->view, q, lk, zero, sec_lo, sec_n, sched + 4 * SCHED_WORDS);
+                    else if (n_sorted) hipLaunchKernelGGL(k_gather<0>, dim3(ctx->query_blocks), block, 0, ctx->aux2, map->view, q, ctx->sp_early.as<uint32_t>(), &d_ctr->n_early, 0u, 0u, sched + 4 * SCHED_WORDS);
                     hipLaunchKernelGGL(k_gather_tile<0>, dim3(ctx->tile_blocks), dim3(64), 0, st, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sched, strips, dbg,
                                        sorted, ctx->sp_groups.as<uint2>());
                 }
@@ -943,6 +951,7 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
             } else {
                 if (use_tiles) {
                     if (sec_n) hipLaunchKernelGGL(k_gather<1>, dim3(ctx->query_blocks), block, 0, ctx->aux2, map->view, q, lk, zero, sec_lo, sec_n, sched + 5 * SCHED_WORDS);
+                    else if (n_sorted) hipLaunchKernelGGL(k_gather<1>, dim3(ctx->query_blocks), block, 0, ctx->aux2, map->view, q, ctx->sp_early.as<uint32_t>(), &d_ctr->n_early, 0u, 0u, sched + 5 * SCHED_WORDS);
                     hipLaunchKernelGGL(k_gather_tile<1>, dim3(ctx->tile_blocks), dim3(64), 0, st, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sched + 2 * SCHED_WORDS, strips, dbg,
                                        sorted, ctx->sp_groups.as<uint2>());
                 }
@@ -979,7 +988,7 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
         if (hipMemcpy(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost) == hipSuccess)
             fprintf(stderr, "[pm] shade points %u (primary %u), groups %u, left to the per-query gather: global %u caustic %u\n", hc.n_sp, n_sp0,
                     hc.n_groups, hc.n_left[0], hc.n_left[1]);
-        fprintf(stderr, "[pm] bounced pixels' shade points in spatial order: %u, in %u groups\n", n_sorted, hc.n_sgroups);
+        fprintf(stderr, "[pm] bounced pixels' shade points in spatial order: %u, in %u groups; %u straight to the per-query kernel\n", n_sorted, hc.n_sgroups, hc.n_early);
         fprintf(stderr, "[pm] lanes handed over, by reason (few photons, spread, radius, |S|, no lane served, -, own shortfall): %u %u %u %u %u %u %u\n", hc.why[1], hc.why[2],
                 hc.why[3], hc.why[4], hc.why[5], hc.why[6], hc.why[7]);
         for (int k = 0; k < 2; k++) {
@@ -1012,12 +1021,12 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
         if (gathered[0]) {
             (void)hipEventElapsedTime(&stats->ms_gather_global, ctx->ev_g[0][0], ctx->ev_g[0][2]);
             (void)hipEventElapsedTime(&stats->ms_group_global, ctx->ev_g[0][0], ctx->ev_g[0][1]);
-            stats->grouped_global = n_primary_sp ? n_primary_sp - ctx->h_ctr->n_left[0] : 0u;
+            stats->grouped_global = n_primary_sp ? n_primary_sp - ctx->h_ctr->n_left[0] - ctx->h_ctr->n_early : 0u;
         }
         if (gathered[1]) {
             (void)hipEventElapsedTime(&stats->ms_gather_caustic, ctx->ev_g[1][0], ctx->ev_g[1][2]);
             (void)hipEventElapsedTime(&stats->ms_group_caustic, ctx->ev_g[1][0], ctx->ev_g[1][1]);
-            stats->grouped_caustic = n_primary_sp ? n_primary_sp - ctx->h_ctr->n_left[1] : 0u;
+            stats->grouped_caustic = n_primary_sp ? n_primary_sp - ctx->h_ctr->n_left[1] - ctx->h_ctr->n_early : 0u;
         }
         (void)hipEventElapsedTime(&stats->ms_resolve, ctx->ev[5], ctx->ev[6]);
         (void)hipEventElapsedTime(&stats->ms_total, ctx->ev[0], ctx->ev[6]);

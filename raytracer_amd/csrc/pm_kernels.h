@@ -29,7 +29,7 @@ struct FrameParams {
     int rank, world;
 };
 
-struct Counters { uint32_t n_sp, n_complex, n_secondary, n_groups, n_left[2], pad, n_sgroups; uint32_t why[8]; unsigned long long tphase[8]; uint32_t ghist[2][32]; };   // n_left[k]: shade points left to the per-query gather of map k
+struct Counters { uint32_t n_sp, n_complex, n_secondary, n_groups, n_left[2], pad, n_sgroups, n_early, n_pieces; uint32_t why[8]; unsigned long long tphase[8]; uint32_t ghist[2][32]; };   // n_left[k]: shade points left to the per-query gather of map k
 
 // shade point queue (SoA)
 struct SPQueue {
@@ -302,12 +302,13 @@ __global__ __launch_bounds__(256) void k_sp_morton(SPQueue q, uint32_t lo, uint3
     vals[i] = lo + i;
 }
 
-// Groups of the sorted shade points: the runs that share an octree cell of about `cell_rel` times the extent of their
-// bounds (a few 63-NN radii), cut into pieces of at most 64.  One thread per run (the thread of its first point; the end
-// of the run by binary search).  A run too short to pay for a shared candidate set goes straight to both maps' lists for
-// the per-query kernel.
-__global__ __launch_bounds__(256) void k_sp_groups(const uint64_t *keys, const uint32_t *sorted, uint32_t n, double cell_rel, uint32_t min_run, uint2 *sgroups,
-                                                    Counters *ctr, uint32_t *left0, uint32_t *left1) {
+// Groups of the sorted shade points.  k_sp_pieces: the runs that share an octree cell of about `cell_rel` times the extent
+// of their bounds (a few 63-NN radii), cut into pieces of at most 64; one thread per run (the thread of its first point;
+// the end of the run by binary search).  k_sp_classify: one wave per piece.  A piece goes to the group kernel when a shared
+// candidate set is likely to pay: enough points, and an expected set size (the group kernel's own estimate, with the mean
+// photon density in place of a centre query) within `est_max`.  The others go to the `early` list: the per-query kernel
+// takes them on a stream of its own right away, beside the group kernels, instead of after them.
+__global__ __launch_bounds__(256) void k_sp_pieces(const uint64_t *keys, uint32_t n, double cell_rel, uint2 *pieces, Counters *ctr) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int level = 1;
@@ -317,15 +318,34 @@ __global__ __launch_bounds__(256) void k_sp_groups(const uint64_t *keys, const u
     if (i > 0 && (keys[i - 1] >> shift) == cell) return;
     uint32_t lo = i + 1, hi = n;                      // first index beyond the run
     while (lo < hi) { uint32_t mid = lo + (hi - lo) / 2; if ((keys[mid] >> shift) == cell) lo = mid + 1; else hi = mid; }
-    const uint32_t cnt = lo - i;
-    if (cnt < min_run) {
-        uint32_t b0 = atomicAdd(&ctr->n_left[0], cnt), b1 = atomicAdd(&ctr->n_left[1], cnt);
-        for (uint32_t j = 0; j < cnt; j++) { left0[b0 + j] = sorted[i + j]; left1[b1 + j] = sorted[i + j]; }
-        return;
+    const uint32_t cnt = lo - i, np = (cnt + 63u) / 64u, per = (cnt + np - 1u) / np;
+    uint32_t g = atomicAdd(&ctr->n_pieces, np);
+    for (uint32_t c = 0; c < cnt; c += per, g++) pieces[g] = make_uint2(i + c, min(per, cnt - c));
+}
+__global__ __launch_bounds__(256) void k_sp_classify(SPQueue q, const uint32_t *sorted, const uint2 *pieces, const uint32_t *bounds, double photons_per_ext2,
+                                                      double est_max, uint32_t min_run, uint2 *sgroups, Counters *ctr, uint32_t *early) {
+    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (w >= ctr->n_pieces) return;
+    const uint2 pc = pieces[w];
+    const uint32_t s = sorted[pc.x + min((uint32_t)lane, pc.y - 1u)];      // idle lanes repeat the last point
+    bool grouped = pc.y >= min_run;
+    if (grouped) {
+        float ext = 0.f;
+        for (int a = 0; a < 3; a++) ext = fmaxf(ext, sp_ord2f(bounds[3 + a]) - sp_ord2f(bounds[a]));
+        const double rho = photons_per_ext2 / fmax((double)ext * (double)ext, 1e-300);   // photons per unit of surface
+        const double rad = sqrt(PM_TILE_BETA2 * 63.0 / (3.14159265 * rho));
+        double e[3];
+        for (int a = 0; a < 3; a++) { double v = q.geo[a * (size_t)q.cap + s]; e[a] = wave_max_f64(v) - wave_min_f64(v) + 2 * rad; }
+        grouped = e[0] * e[1] * e[2] / fmin(e[0], fmin(e[1], e[2])) * rho <= est_max;
     }
-    const uint32_t pieces = (cnt + 63u) / 64u, per = (cnt + pieces - 1u) / pieces;
-    uint32_t g = atomicAdd(&ctr->n_sgroups, pieces);
-    for (uint32_t c = 0; c < cnt; c += per, g++) sgroups[g] = make_uint2(i + c, min(per, cnt - c));
+    if (grouped) { if (lane == 0) sgroups[atomicAdd(&ctr->n_sgroups, 1u)] = pc; }
+    else {
+        uint32_t b0 = 0;
+        if (lane == 0) b0 = atomicAdd(&ctr->n_early, pc.y);
+        b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+        if ((uint32_t)lane < pc.y) early[b0 + (uint32_t)lane] = s;
+    }
 }
 
 // One draw from a work counter per wave.  Out of line on purpose: inlined into the scheduling loop, the
