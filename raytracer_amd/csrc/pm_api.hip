@@ -71,6 +71,7 @@ struct pm_ctx {
     int nprims = 0, stride = 0;
     double yield[2] = {0.60, 0.36};   // stored photons per emission attempt (global, caustic): the reference scene's to begin with, then
                                       // what the last map of this scene showed (sizes the one emission range a map is made from)
+    bool shadow_per_ray = true;       // one lane per shadow ray rather than per shade point (PM_SHADOW_PER_RAY=0: the latter, for A/B runs)
     int scene_mode = SCENE_LDS;   // SCENE_LDS: staged per block; SCENE_GLOBAL: read in place; SCENE_GRID: in place, through the sphere grid
     size_t scene_b = 0;
     DevBuf scene, sgrid;
@@ -341,6 +342,7 @@ extern "C" int pm_scene_upload(pm_ctx *ctx, const pm_prim *prims, int32_t n) {
         if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] scene grid %d x %d x %d, %zu refs for %d spheres, %zu loose primitives\n", G.rx, G.ry, G.rz,
                                         hg.refs.size(), nspheres, hg.loose.size());
     }
+    if (const char *e = getenv("PM_SHADOW_PER_RAY")) ctx->shadow_per_ray = e[0] != '0';
     return PM_OK;
 }
 
@@ -449,7 +451,7 @@ static int build_index(pm_map *map, BuildSlot &sl) {
     hipLaunchKernelGGL(k_cell_boxes_fine, dim3((unsigned)(((1LL << (3 * lmax)) + 255) / 256)), dim3(256), 0, sl.stream, map->pos4.as<float4>(),
                        map->cells.as<uint32_t>(), lmax, sl.bounds.as<uint32_t>(), map->cbox.as<uint64_t>());
     int l = lmax - 1;
-    for (; l > 4; l--)
+    for (; l > 3; l--)
         hipLaunchKernelGGL(k_cell_boxes_up, dim3((unsigned)(((1LL << (3 * l)) + 255) / 256)), dim3(256), 0, sl.stream, map->cells.as<uint32_t>(), l,
                            map->cbox.as<uint64_t>());
     if (l >= 0) hipLaunchKernelGGL(k_cell_boxes_top, dim3(1), dim3(256), 0, sl.stream, map->cells.as<uint32_t>(), l, map->cbox.as<uint64_t>());
@@ -866,7 +868,9 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
     bool gathered[2] = {false, false};
     uint32_t n_primary_sp = 0, n_sorted = 0;
     if (n_sp) {
-        LAUNCH_SCENE(k_shadow, dim3((n_sp + 255) / 256), block, ctx, fp, q, n_sp);
+        // one lane per shadow ray; or (A/B switch) one lane per shade point with its 25 rays in sequence
+        if (ctx->shadow_per_ray) LAUNCH_SCENE(k_shadow_rays, dim3((n_sp + 9) / 10), block, ctx, fp, q, n_sp);
+        else LAUNCH_SCENE(k_shadow, dim3((n_sp + 255) / 256), block, ctx, fp, q, n_sp);
         HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
         // The gather: groups of neighbouring shade points first (k_gather_tile), then one wave per shade point for what
         // the group kernel left and for the shade points of bounced pixels (k_gather).  Both kernels are launched with

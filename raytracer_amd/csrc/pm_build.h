@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void k_cell_boxes_up(const uint32_t *cells, in
     long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c < (1LL << (3 * l))) cell_box_up(cells, l, c, cbox);
 }
-// levels ltop, ltop - 1, ..., 0 in one block (8^ltop <= 4096 cells): one launch instead of one per level.  A small block:
+// levels ltop, ltop - 1, ..., 0 in one block (8^ltop <= 512 cells): one launch instead of one per level.  A small block:
 // beside wide kernels of the frame a 16-wave block waits a long time for a compute unit with room for all of it.
 __global__ __launch_bounds__(256) void k_cell_boxes_top(const uint32_t *cells, int ltop, uint64_t *cbox) {
     for (int l = ltop; l >= 0; l--) {
