@@ -27,7 +27,7 @@ namespace pm {
 #define PM_TILE_BETA2 1.6     // shared squared radius of a group, in units of the centre query's 63rd squared distance
 #endif
 #ifndef PM_TILE_EST_MAX
-#define PM_TILE_EST_MAX 1200   // expected size of the shared set beyond which a group is left to the per-query kernel: one wave
+#define PM_TILE_EST_MAX 1600   // expected size of the shared set beyond which a group is left to the per-query kernel: one wave
                               // would sit on it for many times the average while independent queries spread over the device
 #endif
 #ifndef PM_TS_CAP
