@@ -400,7 +400,7 @@ __device__ __noinline__ uint32_t wave_draw(uint32_t *ctr) {
 }
 
 #ifndef PM_GATHER_GROUP
-#define PM_GATHER_GROUP 4      // consecutive shade points (neighbouring pixels) per draw
+#define PM_GATHER_GROUP 2      // consecutive shade points (neighbours) per draw: the second starts from the first one's ball
 #endif
 constexpr uint32_t SCHED_CHUNK = 1024;   // items per chunk; chunk c belongs to counter c % 64
 constexpr uint32_t SCHED_STRIDE = 32;    // one counter per 128-byte line
