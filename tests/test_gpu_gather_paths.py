@@ -144,3 +144,31 @@ def test_map_from_shards_reports_shortfall_and_overflow(gpu_ctx):
     with pytest.raises(ra.PMError, match="overflowed"):
         m.download()
     m.destroy(); hip.hipFree(d)
+
+
+def test_config3_size_group_gather_equals_per_query_gather(monkeypatch):
+    """BASELINE config 3's sizes on one GPU (pane 7680 x 4320 = 3840 x 2160 at 4 spp, 10M + 10M photons): too large for the
+    oracle, so the property that does not depend on size -- the group kernel and the per-query kernel are two exact
+    searches and must agree bit for bit -- is checked on the whole pane, and the row split over two ranks on top."""
+    import raytracer_amd as ra
+    w, h, n, seed = 7680, 4320, 10_000_000, 12345
+    panes = []
+    for tile in (True, False):
+        monkeypatch.setenv("PM_GATHER_TILE", "1" if tile else "0")
+        ctx = ra.Context(0)
+        try:
+            ctx.upload_scene(ra.default_scene())
+            g, c = ctx.create_map(0, n, seed, wait=False), ctx.create_map(1, n, seed, wait=False)
+            pane, st = ctx.render(g, c, ctx.params(w, h, seed))
+            if tile:
+                assert st.grouped_global > 0.8 * st.absorb_points
+                parts = np.zeros_like(pane)
+                for rank in range(2):
+                    ctx.render(g, c, ctx.params(w, h, seed, rank=rank, world=2), pane=parts)
+                assert np.array_equal(parts, pane)
+            panes.append(pane)
+            g.destroy(); c.destroy()
+        finally:
+            ctx.close()
+    assert np.array_equal(panes[0], panes[1])
+    assert len(np.unique(panes[0])) > 1000
