@@ -1,29 +1,72 @@
-// main.cpp -- `raytracer cores width height samples`, the reference's command line (src/Main.cpp:14-41)
-// on the GPU backend.  Environment (not in the reference): RAYTRACER_SEED fixes the random streams
-// (default: clock, like the reference), RAYTRACER_PHOTONS sets the photons per map (default 2048).
+// main.cpp -- the renderer's command line on the GPU backend.
+//
+//   raytracer [options] <cores> <width> <height> <samples>
+//
+// The four positional arguments and the three refusals are the reference's (src/Main.cpp:14-41): same wording, same
+// exit status 0, nothing written.  Options the reference lacks (its photon count is a compile-time constant and its
+// random engine is seeded from the clock):
+//   --photons N   photons per map (also RAYTRACER_PHOTONS; default 2048, the reference's NUM_PHOTONS)
+//   --seed S      fixes the random streams (also RAYTRACER_SEED; default: the clock, like the reference)
+//   --out FILE    image file (default raytraced.png, the reference's name)
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
 
 #include "raytrace_api.h"
 
+namespace {
+
+struct Options {
+    int cores = 1, width = 0, height = 0, samples = 0;
+    long long photons = -1;
+    bool have_seed = false;
+    long long seed = 0;
+    std::string out = "raytraced.png";
+};
+
+// One line per way the reference turns a command line down, in the order it checks them.
+struct Refusal { bool (*applies)(const Options &); const char *message; };
+const Refusal kRefusals[] = {
+    {[](const Options &o) { return o.width / 16 != o.height / 9; }, "Image dimensions must be a 16:9 ratio.\n"},
+    {[](const Options &o) { return o.samples < 0 || o.width < 0 || o.height < 0; }, "Dimensions and samples must be positive\n"},
+};
+const char kUsage[] = "Usage: ./raytracer [# cores] [width] [height] [samples]\n";
+
+// Splits argv into options and the positional numbers; false = malformed option.
+bool parse(int argc, char *argv[], Options &o, std::vector<const char *> &positional) {
+    if (const char *e = std::getenv("RAYTRACER_SEED")) { o.have_seed = true; o.seed = std::atoll(e); }
+    if (const char *e = std::getenv("RAYTRACER_PHOTONS")) o.photons = std::atoll(e);
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        const bool wants_value = a == "--photons" || a == "--seed" || a == "--out";
+        if (!wants_value) { positional.push_back(argv[i]); continue; }
+        if (i + 1 >= argc) return false;
+        const char *v = argv[++i];
+        if (a == "--photons") o.photons = std::atoll(v);
+        else if (a == "--seed") { o.have_seed = true; o.seed = std::atoll(v); }
+        else o.out = v;
+    }
+    return true;
+}
+
+}  // namespace
+
 int main(int argc, char *argv[]) {
-    if (argc != 5) {
-        printf("Usage: ./raytracer [# cores] [width] [height] [samples]\n");
+    Options o;
+    std::vector<const char *> pos;
+    if (!parse(argc, argv, o, pos) || pos.size() != 4) {
+        std::fputs(kUsage, stdout);
         return 0;
     }
-    int cores = atoi(argv[1]), width = atoi(argv[2]), height = atoi(argv[3]), samples = atoi(argv[4]);
-    if (cores < 1) cores = 1;
-    if (width / 16 != height / 9) {
-        printf("Image dimensions must be a 16:9 ratio.\n");
-        return 0;
-    }
-    if (samples < 0 || width < 0 || height < 0) {
-        printf("Dimensions and samples must be positive\n");
-        return 0;
-    }
-    if (const char *s = getenv("RAYTRACER_SEED")) randutil::init(atoll(s));
-    if (const char *p = getenv("RAYTRACER_PHOTONS")) raytrace::setPhotonCounts(atoi(p), atoi(p));
-    scheduler::startWorkers(cores);
-    raytrace::render("raytraced.png", width, height, samples);
+    o.cores = std::atoi(pos[0]) < 1 ? 1 : std::atoi(pos[0]);
+    o.width = std::atoi(pos[1]); o.height = std::atoi(pos[2]); o.samples = std::atoi(pos[3]);
+    for (const Refusal &r : kRefusals)
+        if (r.applies(o)) { std::fputs(r.message, stdout); return 0; }
+    if (o.have_seed) randutil::init(o.seed);
+    if (o.photons >= 0) raytrace::setPhotonCounts((int32)o.photons, (int32)o.photons);
+    scheduler::startWorkers(o.cores);          // opens the GPU context; `cores` has no other meaning here
+    raytrace::render(o.out.c_str(), o.width, o.height, o.samples);
     return 0;
 }
