@@ -25,7 +25,12 @@ def test_cli_argument_checks(tmp_path):
     assert r.returncode == 0 and r.stdout == "Image dimensions must be a 16:9 ratio.\n"
     r = run([8, 1280, 720, -1], tmp_path)
     assert r.returncode == 0 and r.stdout == "Dimensions and samples must be positive\n"
-    assert not os.path.exists(tmp_path / "raytraced.png")
+    # options the reference lacks: a dangling option is a usage error, a well-formed one does not disturb the checks
+    r = run(["--seed"], tmp_path)
+    assert r.returncode == 0 and r.stdout.startswith("Usage:")
+    r = run(["--photons", 10, "--out", "x.png", 8, 1440, 1440, 1], tmp_path)
+    assert r.returncode == 0 and r.stdout == "Image dimensions must be a 16:9 ratio.\n"
+    assert not os.path.exists(tmp_path / "raytraced.png") and not os.path.exists(tmp_path / "x.png")
 
 
 @pytest.mark.gpu
