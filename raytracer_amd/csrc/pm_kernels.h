@@ -512,7 +512,6 @@ __global__ __launch_bounds__(64) void k_gather_tile(MapView m_in, SPQueue q, con
         const bool ok = tile_gather<KIND>(&tb, S, m, p, nrm, active, r_scale, R, G, B, why, const_cast<unsigned long long *>(ctr->tphase));
         if (ok) { out[0 * (size_t)q.cap + s] = R; out[1 * (size_t)q.cap + s] = G; out[2 * (size_t)q.cap + s] = B; }
         bool dead = active && !ok;
-        const bool todo = false;
         if (dbg) {   // diagnostic: lanes handed over, by reason (7 = the lane's own shortfall)
             const int lost = __popcll(__ballot(dead));
             if (lane == 0 && lost) atomicAdd(const_cast<uint32_t *>(&ctr->why[why != 0 ? (why & 7) : 7]), (uint32_t)lost);
@@ -520,7 +519,6 @@ __global__ __launch_bounds__(64) void k_gather_tile(MapView m_in, SPQueue q, con
 #ifdef PM_TILE_STAMPS
         if (lane == 0) { unsigned long long dt = __builtin_amdgcn_s_memtime() - tg0; atomicAdd(const_cast<uint32_t *>(&ctr->ghist[KIND][63 - __clzll((long long)(dt | 1ULL))]), 1u); }
 #endif
-        if (todo) dead = true;
         const unsigned long long lm = __ballot(dead);
         if (lm) {
             uint32_t base = 0;

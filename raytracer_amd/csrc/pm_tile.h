@@ -225,11 +225,11 @@ __device__ inline void tile_pass(float *stage, const Strip &S, int ns, float pxf
     wave_lds_fence();
 }
 
-// One group, or a part of it.  p, nrm: this lane's shade point; active: lane takes part (idle lanes must hold the point of
+// One group.  p, nrm: this lane's shade point; active: lane takes part (idle lanes must hold the point of
 // some active lane, so that the bounding box is that of the active ones).  r_scale: the 63rd squared distance of a query
 // in the neighbourhood, or <= 0 to have one made at the centre of the box (then returned).
-// Returns, per lane, whether R, G, B hold the lane's radiance estimate.  why = 2 or 4 on return says that the part is
-// too spread out for one shared set (nothing was computed): the caller may try again with fewer lanes.  A lane that
+// Returns, per lane, whether R, G, B hold the lane's radiance estimate.  why = 2 or 4 on return says that the group is
+// too spread out for one shared set (nothing was computed): all of it goes to the per-query kernel.  A lane that
 // gets false otherwise (fewer than 63 photons inside the shared radius, a crossing bin too full to rank) goes to the
 // per-query kernel.
 #ifdef PM_TILE_STAMPS
@@ -268,9 +268,6 @@ __device__ inline bool tile_gather(TileBuf *tb, const Strip &S, const MapView &m
         double e[3] = {qhi.x - qlo.x, qhi.y - qlo.y, qhi.z - qlo.z};
         double rad = sqrt(L), e_min = fmin(e[0], fmin(e[1], e[2]));
         double area = (e[0] + 2 * rad) * (e[1] + 2 * rad) * (e[2] + 2 * rad) / (e_min + 2 * rad);
-#ifdef PM_TILE_PRINT
-        if (0) printf("blk %d e %.4f %.4f %.4f rad %.4f r_scale %.6f est %.1f nact %d\n", (int)blockIdx.x, e[0], e[1], e[2], rad, r_scale, area * 63.0 / (3.14159 * r_scale), (int)__popcll(__ballot(active)));
-#endif
         if (area * (double)KNN_K > (double)PM_TILE_EST_MAX * 3.14159 * r_scale) { why = 2; return false; }
     }
     // 2. the shared candidate set: everything closer than sqrt(L) to the box, so everything closer than that to any lane's
