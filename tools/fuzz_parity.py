@@ -1,12 +1,12 @@
 """Randomised parity sweep on the GPU box: random frame sizes, photon counts, seeds, cameras, light colours and flags on
-the three scenes, every pane compared bit for bit with the oracle's.  usage: fuzz_parity.py [cases] [seed]"""
+the three scenes, every pane compared bit for bit with the oracle's.  usage: fuzz_parity.py [cases] [seed] [large]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import raytracer_amd as ra
 from oracle import orc_py as orc
 
-def sweep(cases, seed, verbose=True):
+def sweep(cases, seed, verbose=True, large=False):
     """Runs `cases` random configurations; returns the list of mismatch descriptions (empty = parity)."""
     rng = np.random.default_rng(seed)
     scenes = {"default": ra.default_scene(), "caustics": ra.caustics_scene(), "spheres300": ra.many_spheres_scene(300, 5)}
@@ -20,8 +20,12 @@ def sweep(cases, seed, verbose=True):
         for k in range(cases):
             name = list(scenes)[int(rng.integers(0, 3))]
             ctx, scene = ctxs[name], scenes[name]
-            w, h = int(rng.integers(1, 300)), int(rng.integers(1, 200))
-            n = int(rng.choice([0, 5, 63, 64, 500, 3000, 20000, 60000]))
+            if large:   # big octrees, mostly grouped gathers
+                w, h = int(rng.integers(300, 1000)), int(rng.integers(300, 700))
+                n = int(rng.choice([100000, 300000, 1000000]))
+            else:
+                w, h = int(rng.integers(1, 300)), int(rng.integers(1, 200))
+                n = int(rng.choice([0, 5, 63, 64, 500, 3000, 20000, 60000]))
             sd = int(rng.integers(0, 2 ** 40))
             flags = int(rng.choice([0, 0, 0, 1, 2, 4]))
             cam = (float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3)), float(rng.uniform(-15, -6)))
@@ -51,6 +55,6 @@ def sweep(cases, seed, verbose=True):
 
 if __name__ == "__main__":
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    found = sweep(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    found = sweep(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 1, large=len(sys.argv) > 3 and sys.argv[3] == "large")
     print(f"done: {n_cases} cases, {len(found)} mismatches")
     sys.exit(1 if found else 0)
