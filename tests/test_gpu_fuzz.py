@@ -15,3 +15,12 @@ def test_randomised_parity_sweep():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.sweep(60, 2026, verbose=False) == []
+
+
+def test_randomised_knn_and_gather_sweep():
+    """tools/fuzz_knn.py: random maps of both kinds (1 .. 400 000 photons), query points on photons, near them, in mid air and
+    far outside the scene, arbitrary and axis-aligned normals: pm_knn_gather and pm_knn_query against the oracle."""
+    spec = importlib.util.spec_from_file_location("fuzz_knn", os.path.join(ROOT, "tools", "fuzz_knn.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.sweep(40, 99, verbose=False) == []
