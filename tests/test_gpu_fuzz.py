@@ -24,3 +24,12 @@ def test_randomised_knn_and_gather_sweep():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.sweep(40, 99, verbose=False) == []
+
+
+def test_randomised_shard_sweep():
+    """tools/fuzz_shards.py: 1 .. 8 ranks' shards cut by the frame's own rule, assembled on the device, and ranges cut at
+    random through pm_emit_range, against the map one rank emits alone (three scenes, both kinds)."""
+    spec = importlib.util.spec_from_file_location("fuzz_shards", os.path.join(ROOT, "tools", "fuzz_shards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.sweep(30, 5, verbose=False) == []
