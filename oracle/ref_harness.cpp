@@ -12,7 +12,12 @@
  *   5. full and direct-only panes       traceRay
  * and writes the golden vectors that tests/ replay without the reference.
  *
- *   usage: ref_harness <outdir> [width height nphotons seed]
+ *   usage: ref_harness <outdir> [width height nphotons seed [write|nowrite [scene]]]
+ *
+ * scene: default (src/Image.cpp:20-28), or one of the synthetic scenes below, built with the reference's own
+ * constructors -- caustics (BASELINE config 4), spheres100 (config 5's generator at 100 spheres), mixed100 (100
+ * large overlapping spheres, every fourth one glass, every fourth one a mirror).  Their flattened pm_prim arrays
+ * are written next to the vectors (scene_<name>.bin) so the tests replay exactly the scene the reference traced.
  */
 #include <algorithm>
 #include <cmath>
@@ -62,6 +67,68 @@ static Scene *make_ref_scene() {
     return scene;
 }
 
+static void add_walls(Scene *scene) {
+    Scene *d = make_ref_scene();
+    for (int i = 0; i < 5; i++) scene->objects[i] = d->objects[i];
+}
+
+/* BASELINE config 4 (raytracer_amd/scenes.py, caustics_scene): the walls + five spheres of the reference's glass */
+static Scene *make_caustics_scene() {
+    static const double g[5][4] = {{2.0, -3.5, 3.0, 1.5}, {-2.0, -3.5, 5.0, 1.5}, {0.0, -4.0, 7.5, 1.0}, {-3.0, -1.0, 8.0, 0.8}, {2.5, 0.5, 6.5, 1.0}};
+    Scene *scene = new Scene(10);
+    add_walls(scene);
+    for (int i = 0; i < 5; i++) {
+        scene->objects[5 + i] = new SphereObject(g[i][0], g[i][1], g[i][2], g[i][3], 0xFFFFFFFF, 0.0, 0.1, 0.9, 0.0);
+        scene->objects[5 + i]->refraction = 2.5;
+    }
+    return scene;
+}
+
+/* the counter-based uniform stream of raytracer_amd/scenes.py: u_j = (mix64(mix64(seed) + j*GOLD) >> 11) * 2^-53, j >= 1 */
+static double scene_uniform(uint64_t seed, uint64_t j) {
+    return (double)(orc_mix64(orc_mix64(seed) + j * ORC_GOLD) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+/* the walls + n spheres from seven uniforms each (raytracer_amd/scenes.py, many_spheres_scene); mixed: every fourth
+ * sphere the reference's glass, every fourth one its mirror (src/Image.cpp:26-28) */
+static Scene *make_spheres_scene(int n, uint64_t seed, double rmin, double rspan, bool mixed) {
+    Scene *scene = new Scene(5 + n);
+    add_walls(scene);
+    for (int i = 0; i < n; i++) {
+        double u[7];
+        for (int k = 0; k < 7; k++) u[k] = scene_uniform(seed, (uint64_t)i * 7 + k + 1);
+        uint32 col = 0xFF000000u;
+        for (int k = 0; k < 3; k++) col |= (uint32)(64 + (int)floor(u[4 + k] * 192.0)) << (16 - 8 * k);
+        double x = u[0] * 9.0 - 4.5, y = u[1] * 9.0 - 4.5, z = u[2] * 9.0 + 0.5, r = rmin + u[3] * rspan;
+        if (mixed && i % 4 == 0) {
+            scene->objects[5 + i] = new SphereObject(x, y, z, r, col, 0.0, 0.1, 0.9, 0.0);
+            scene->objects[5 + i]->refraction = 2.5;
+        } else if (mixed && i % 4 == 1) {
+            scene->objects[5 + i] = new SphereObject(x, y, z, r, col, 0.0, 1.0, 0.0, 0.0);
+        } else {
+            scene->objects[5 + i] = new SphereObject(x, y, z, r, col, 0.4, 0.0, 0.0, 1.0);
+        }
+    }
+    return scene;
+}
+
+/* a reference object as the pm_prim record the oracle and the product take */
+static orc_prim flatten(SceneObject *o) {
+    orc_prim p; memset(&p, 0, sizeof(p));
+    if (SphereObject *s = dynamic_cast<SphereObject *>(o)) {
+        p.kind = 0; p.radius = s->radius; p.dx = s->dx; p.dy = s->dy; p.dz = s->dz;
+    } else {
+        PlaneObject *pl = dynamic_cast<PlaneObject *>(o);
+        p.kind = 1; p.min_bound = pl->min_bound; p.max_bound = pl->max_bound;
+    }
+    p.x = o->x; p.y = o->y; p.z = o->z;
+    p.red = o->red; p.green = o->green; p.blue = o->blue;
+    p.absorb_chance = o->absorb_chance; p.diffuse_chance = o->diffuse_chance;
+    p.specular_chance = o->specular_chance; p.transmission_chance = o->transmission_chance;
+    p.refraction = o->refraction; p.specular_coeff = o->specular_coeff;
+    return p;
+}
+
 static int obj_index(Scene *s, SceneObject *o) {
     if (!o) return -1;
     for (int i = 0; i < s->size; i++) if (s->objects[i] == o) return i;
@@ -90,24 +157,40 @@ static uint64_t splitmix_local(uint64_t &s) { s += ORC_GOLD; return orc_mix64(s)
 static double urand(uint64_t &s) { return (double)(splitmix_local(s) >> 11) * (1.0 / 9007199254740992.0); }
 
 int main(int argc, char **argv) {
-    if (argc < 2) { printf("usage: ref_harness <outdir> [width height nphotons seed]\n"); return 2; }
+    if (argc < 2) { printf("usage: ref_harness <outdir> [width height nphotons seed [write|nowrite [scene]]]\n"); return 2; }
     std::string out = argv[1];
     int W = argc > 2 ? atoi(argv[2]) : 160, H = argc > 3 ? atoi(argv[3]) : 90;
     int NPH = argc > 4 ? atoi(argv[4]) : 2048;
     uint64_t seed = argc > 5 ? strtoull(argv[5], nullptr, 10) : 12345ULL;
     bool write_golden = !(argc > 6 && strcmp(argv[6], "nowrite") == 0);
-    std::string tag = "_" + std::to_string(W) + "x" + std::to_string(H) + "_n" + std::to_string(NPH);
+    std::string scene_name = argc > 7 ? argv[7] : "default";
+    bool is_default = scene_name == "default";
+    std::string sfx = is_default ? "" : "_" + scene_name;      /* golden files of the default scene keep their names */
+    std::string tag = sfx + "_" + std::to_string(W) + "x" + std::to_string(H) + "_n" + std::to_string(NPH);
+    std::string ntag = sfx + "_n" + std::to_string(NPH);
 
-    Scene *scene = make_ref_scene();
-    orc_prim prims[7];
-    orc_default_scene(prims);
+    Scene *scene = nullptr;
+    if (is_default) scene = make_ref_scene();
+    else if (scene_name == "caustics") scene = make_caustics_scene();
+    else if (scene_name == "spheres100") scene = make_spheres_scene(100, 2024, 0.02, 0.06, false);
+    else if (scene_name == "mixed100") scene = make_spheres_scene(100, 77, 0.15, 0.45, true);
+    else { printf("unknown scene %s\n", scene_name.c_str()); return 2; }
+    const int NP = scene->size;
+    std::vector<orc_prim> prim_store(NP);
+    for (int i = 0; i < NP; i++) prim_store[i] = flatten(scene->objects[i]);
+    orc_prim *prims = prim_store.data();
+    if (is_default) {
+        orc_prim dflt[7];
+        orc_default_scene(dflt);
+        CHECK(NP == 7 && memcmp(dflt, prims, sizeof(dflt)) == 0, "flattened default scene != orc_default_scene");
+    }
     Vec3 camera(0, 0, -12);
     double cam[3] = {0, 0, -12};
     Vec3 light_color(0.6, 0.6, 0.6);
     double lc[3] = {0.6, 0.6, 0.6};
 
     /* ---- 0. scene flattening ---- */
-    for (int i = 0; i < 7; i++) {
+    for (int i = 0; i < NP; i++) {
         SceneObject *o = scene->objects[i];
         CHECK(o->x == prims[i].x && o->y == prims[i].y && o->z == prims[i].z, "prim %d position", i);
         CHECK(o->red == prims[i].red && o->green == prims[i].green && o->blue == prims[i].blue, "prim %d colour", i);
@@ -115,10 +198,10 @@ int main(int argc, char **argv) {
               o->specular_chance == prims[i].specular_chance && o->transmission_chance == prims[i].transmission_chance &&
               o->refraction == prims[i].refraction && o->specular_coeff == prims[i].specular_coeff, "prim %d material", i);
     }
-    if (write_golden) write_file(out + "/scene_default.bin", prims, sizeof(prims));
+    if (write_golden) write_file(out + "/scene_" + scene_name + ".bin", prims, (size_t)NP * sizeof(orc_prim));
 
-    /* ---- 1. intersection KATs ---- */
-    {
+    /* ---- 1. intersection KATs (default scene's objects + a moving sphere) ---- */
+    if (is_default) {
         /* record: prim, src[3], dir[3], dt, hit, res[3], nrm[3] = 15 doubles */
         const int NK = 3000;
         std::vector<double> kat;
@@ -173,9 +256,9 @@ int main(int argc, char **argv) {
     std::vector<int32_t> ids((size_t)W * H);
     std::vector<double> hitp((size_t)W * H * 3), hitn((size_t)W * H * 3);
     {
-        orc_primary_hits(prims, 7, W, H, cam, seed, 0, H, ids.data(), hitp.data(), hitn.data());
+        orc_primary_hits(prims, NP, W, H, cam, seed, 0, H, ids.data(), hitp.data(), hitn.data());
         uint64_t K = orc_stream_key(seed, ORC_KIND_PIXEL);
-        long hist[8] = {0};
+        std::vector<long> hist(NP + 1, 0);
         for (int y = 0; y < H; y++)
             for (int x = 0; x < W; x++) {
                 uint64_t pixel = (uint64_t)x + (uint64_t)y * W;
@@ -204,7 +287,8 @@ int main(int argc, char **argv) {
                 hist[rid + 1]++;
             }
         printf("[2] primary hits %dx%d: miss %ld, ids", W, H, hist[0]);
-        for (int i = 1; i < 8; i++) printf(" %ld", hist[i]);
+        for (int i = 1; i <= NP && i <= 12; i++) printf(" %ld", hist[i]);
+        if (NP > 12) { long rest = 0; for (int i = 13; i <= NP; i++) rest += hist[i]; printf(" ... (+%ld on the other %d)", rest, NP - 12); }
         printf(", failures so far %d\n", g_fail);
         if (write_golden) {
             std::vector<int8_t> ids8(ids.begin(), ids.end());
@@ -222,7 +306,7 @@ int main(int argc, char **argv) {
     for (int kind = 0; kind < 2; kind++) {
         orc_tape tape; orc_tape_init(&tape);
         oph[kind].resize(NPH);
-        uint64_t attempts = orc_emit(prims, 7, kind, seed, NPH, ORC_TRIG_LIBM, lc, oph[kind].data(), &tape);
+        uint64_t attempts = orc_emit(prims, NP, kind, seed, NPH, ORC_TRIG_LIBM, lc, oph[kind].data(), &tape);
         ref_tape_set(tape.v, tape.n);
         uint64_t pivot_seed = seed * 2 + kind;
         ref_pivot_set(pivot_seed);
@@ -256,9 +340,9 @@ int main(int argc, char **argv) {
         printf("[3] emission kind %d: %d photons from %llu attempts, %zu draws, kd depth %d, failures so far %d\n", kind, NPH,
                (unsigned long long)attempts, tape.n, rdepth, g_fail);
         if (write_golden) {
-            write_file(out + "/photons_kind" + std::to_string(kind) + "_n" + std::to_string(NPH) + ".bin", oph[kind].data(), (size_t)NPH * 32);
+            write_file(out + "/photons_kind" + std::to_string(kind) + ntag + ".bin", oph[kind].data(), (size_t)NPH * 32);
             uint64_t meta[2] = {attempts, (uint64_t)tape.n};
-            write_file(out + "/photons_kind" + std::to_string(kind) + "_n" + std::to_string(NPH) + "_meta.bin", meta, 16);
+            write_file(out + "/photons_kind" + std::to_string(kind) + ntag + "_meta.bin", meta, 16);
         }
         orc_tape_free(&tape);
     }
@@ -312,7 +396,7 @@ int main(int argc, char **argv) {
             }
         printf("[4] k-NN: %d queries x 2 maps; reference result set != exact k-NN set in %ld queries (SURVEY A.19); failures so far %d\n",
                NQ, set_mismatch, g_fail);
-        if (write_golden) {
+        if (write_golden && is_default) {      /* the k-NN search does not depend on the scene: checked above, stored once */
             write_file(out + "/knn_points" + tag + ".bin", qp.data(), qp.size() * 8);
             write_file(out + "/knn_normals" + tag + ".bin", qn.data(), qn.size() * 8);
             write_file(out + "/knn_ref_idx" + tag + ".bin", gidx.data(), gidx.size() * 4);
@@ -339,9 +423,9 @@ int main(int argc, char **argv) {
             for (int x = 0; x < W; x++) {
                 orc_tape tape; orc_tape_init(&tape);
                 size_t o = (size_t)y * W + x;
-                pane_orc[o] = orc_trace_pixel(prims, 7, omap[0], omap[1], &rp, x, y, &tape, &st);
+                pane_orc[o] = orc_trace_pixel(prims, NP, omap[0], omap[1], &rp, x, y, &tape, &st);
                 orc_render_params rc = rp; rc.order = ORC_ORDER_CANONICAL;
-                pane_can[o] = orc_trace_pixel(prims, 7, omap[0], omap[1], &rc, x, y, nullptr, nullptr);
+                pane_can[o] = orc_trace_pixel(prims, NP, omap[0], omap[1], &rc, x, y, nullptr, nullptr);
                 if (pass == 0) {
                     ref_tape_set(tape.v, tape.n);
                     Vec3 ray(0, 0, 0), ray_source(&camera);
