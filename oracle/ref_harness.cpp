@@ -16,7 +16,8 @@
  *
  * scene: default (src/Image.cpp:20-28), or one of the synthetic scenes below, built with the reference's own
  * constructors -- caustics (BASELINE config 4), spheres100 (config 5's generator at 100 spheres), mixed100 (100
- * large overlapping spheres, every fourth one glass, every fourth one a mirror).  Their flattened pm_prim arrays
+ * large overlapping spheres, every fourth one glass, every fourth one a mirror), moving100 (the same recipe with two
+ * thirds of the spheres in linear motion, src/Scene.cpp:68-85).  Their flattened pm_prim arrays
  * are written next to the vectors (scene_<name>.bin) so the tests replay exactly the scene the reference traced.
  */
 #include <algorithm>
@@ -91,7 +92,7 @@ static double scene_uniform(uint64_t seed, uint64_t j) {
 
 /* the walls + n spheres from seven uniforms each (raytracer_amd/scenes.py, many_spheres_scene); mixed: every fourth
  * sphere the reference's glass, every fourth one its mirror (src/Image.cpp:26-28) */
-static Scene *make_spheres_scene(int n, uint64_t seed, double rmin, double rspan, bool mixed) {
+static Scene *make_spheres_scene(int n, uint64_t seed, double rmin, double rspan, bool mixed, bool moving = false) {
     Scene *scene = new Scene(5 + n);
     add_walls(scene);
     for (int i = 0; i < n; i++) {
@@ -107,6 +108,12 @@ static Scene *make_spheres_scene(int n, uint64_t seed, double rmin, double rspan
             scene->objects[5 + i] = new SphereObject(x, y, z, r, col, 0.0, 1.0, 0.0, 0.0);
         } else {
             scene->objects[5 + i] = new SphereObject(x, y, z, r, col, 0.4, 0.0, 0.0, 1.0);
+        }
+        if (moving && i % 3 != 2) {       /* linear motion over the exposure like src/Image.cpp:30, up to 0.6 per axis; a third stay still */
+            SphereObject *s = static_cast<SphereObject *>(scene->objects[5 + i]);
+            s->dx = scene_uniform(seed + 1, (uint64_t)i * 3 + 1) * 1.2 - 0.6;
+            s->dy = scene_uniform(seed + 1, (uint64_t)i * 3 + 2) * 1.2 - 0.6;
+            s->dz = scene_uniform(seed + 1, (uint64_t)i * 3 + 3) * 1.2 - 0.6;
         }
     }
     return scene;
@@ -174,6 +181,7 @@ int main(int argc, char **argv) {
     else if (scene_name == "caustics") scene = make_caustics_scene();
     else if (scene_name == "spheres100") scene = make_spheres_scene(100, 2024, 0.02, 0.06, false);
     else if (scene_name == "mixed100") scene = make_spheres_scene(100, 77, 0.15, 0.45, true);
+    else if (scene_name == "moving100") scene = make_spheres_scene(100, 91, 0.15, 0.45, true, true);
     else { printf("unknown scene %s\n", scene_name.c_str()); return 2; }
     const int NP = scene->size;
     std::vector<orc_prim> prim_store(NP);

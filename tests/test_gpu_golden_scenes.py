@@ -1,5 +1,5 @@
 """GPU parity, through the C-ABI, against what the COMPILED REFERENCE produced on scenes other than its Cornell box
-(tests/golden/*_{caustics,spheres100,mixed100}_*, see tests/test_oracle_golden_scenes.py and oracle/ref_harness.cpp).
+(tests/golden/*_{caustics,spheres100,mixed100,moving100}_*, see tests/test_oracle_golden_scenes.py and oracle/ref_harness.cpp).
 The two 100-sphere scenes are above the sphere grid's threshold, so the grid is held to the reference's own
 Scene::intersect here; each scene is also run with the grid switched off."""
 import os
@@ -11,7 +11,7 @@ from .conftest import golden, psnr
 
 pytestmark = pytest.mark.gpu
 
-SCENES = ["caustics", "spheres100", "mixed100"]
+SCENES = ["caustics", "spheres100", "mixed100", "moving100"]
 W, H, N, SEED = 96, 54, 2048, 4242
 
 

@@ -1,18 +1,19 @@
 """CPU tests: the oracle against the compiled reference on scenes other than the Cornell box of src/Image.cpp.
 
-oracle/ref_harness.cpp builds three more scenes with the reference's own SphereObject / PlaneObject constructors,
+oracle/ref_harness.cpp builds four more scenes with the reference's own SphereObject / PlaneObject constructors,
 runs Scene::intersect, createPhotonMap / createCausticPhotonMap and traceRay on them under tape replay, checks the
 restatement bit for bit in-process (tests/golden/REPORT_<scene>_*.txt) and writes the vectors replayed here:
   caustics    BASELINE config 4: five spheres of the reference's glass
   spheres100  BASELINE config 5's generator at 100 spheres
   mixed100    100 large overlapping spheres, every fourth one glass, every fourth one a mirror
+  moving100   the same recipe, two thirds of the spheres in linear motion over the exposure (dt)
 The flattened scenes (scene_<name>.bin) are what the reference traced; the Python generators must reproduce them."""
 import numpy as np
 import pytest
 
 from .conftest import golden
 
-SCENES = ["caustics", "spheres100", "mixed100"]
+SCENES = ["caustics", "spheres100", "mixed100", "moving100"]
 W, H, N, SEED = 96, 54, 2048, 4242
 
 
