@@ -49,6 +49,30 @@ def pmc_traffic(kernel):
     return None, "no PMC summary found"
 
 
+# One SIMD issues an FP64 wave-instruction every ~2.2 ns when all of them are busy (profiles/r01/valu_rates.txt): 1024 SIMDs.
+VALU_PEAK_GINSTR_S = 1024 / 2.2
+
+
+def pmc_valu_issue(kernel, launch_ms):
+    """What actually bounds the gather kernels: vector instructions issued per second, from the
+    committed SQ_INSTS_VALU count of one launch of `kernel` over the launch time measured live, against the measured
+    issue rate of the whole device.  The other map's kernel shares the device during that time."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_per_dispatch_avg.json")
+    try:
+        with open(path) as f:
+            pmc = json.load(f)
+        for name, c in pmc.items():
+            if kernel in name and "SQ_INSTS_VALU" in c and launch_ms > 0:
+                ach = c["SQ_INSTS_VALU"] / (launch_ms * 1e-3) / 1e9
+                return {"achieved": ach, "peak": VALU_PEAK_GINSTR_S, "unit": "G wave-instr/s", "frac": ach / VALU_PEAK_GINSTR_S,
+                        "note": "SQ_INSTS_VALU per launch from profiles/r01/pmc_per_dispatch_avg.json (default scene; not collected live) "
+                                "/ live launch time; peak = 1024 SIMDs x one FP64 instruction per 2.2 ns (profiles/r01/valu_rates.txt); "
+                                "the two maps' kernels run side by side, each taking its share of that peak"}
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(frame, args, cores, scene):
     """Oracle ("port") on the host cores: every `stride`-th row of the same frame, same photon maps."""
     import numpy as np
@@ -180,7 +204,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "note": f"algorithmic bytes = {ALGO_BYTES_PER_GATHER} B x {int(dom_units)} gathers answered per launch; avg launch {dom_ms:.3f} ms "
-                                 f"(HIP events on the stream the kernel is launched on; the other map's gather runs beside it on a second stream)"},
+                                 f"(HIP events on the stream the kernel is launched on; the other map's gather runs beside it on a second stream)",
+                         "valu_issue": pmc_valu_issue(("k_gather_tile<0>", "k_gather_tile<1>")[k], dom_ms)
+                         if (args.scene, args.width, args.height, args.photons) == ("default", 1440, 1440, 1000000) else None},
         }
         if not args.no_cpu_baseline and world == 1:
             cores = args.cpu_cores or min(os.cpu_count() or 1, 16)
