@@ -264,20 +264,54 @@ __device__ inline double byte_over_255(int x) {
     return __builtin_fma(res, inv, q);
 }
 
+// x / d for one d and many x.  The compiler's IEEE division is v_div_scale (both operands), v_rcp_f64, two Newton steps on
+// the reciprocal, then per quotient a product, an exact residual and a final fma (v_div_fmas), and v_div_fixup; the scaling
+// and the fix-up are the identity for ordinary operands.  Here the part that depends on d alone is done once; the quotient
+// is then the compiler's own, bit for bit, for d in [2^-100, 2^100] and 2^-900 <= x <= d; for smaller x it may differ from
+// it below 2^-800, which a caller that forms 1 - x / d cannot see.  Any other d takes the plain division.
+struct RDiv { double d, y; bool ok; };
+__device__ inline RDiv rdiv_make(double d) {
+    RDiv r;
+    r.d = d;
+    r.ok = d >= 0x1p-100 && d <= 0x1p100;
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    r.y = __builtin_fma(y, e, y);
+    return r;
+}
+__device__ inline double rdiv(const RDiv &r, double x) {
+    if (__builtin_expect(!r.ok, 0)) return x / r.d;
+    const double q = x * r.y;
+    return __builtin_fma(__builtin_fma(-r.d, q, x), r.y, q);
+}
+
 // One photon's term of the radiance sums: src/Raytrace.cpp:100-125 (global), :139-164 (caustic).
-// s = shade point - photon position (the reference's `dist`), pd2 = |s|^2, r = the 63rd-smallest pd2.
+// s = shade point - photon position (the reference's `dist`), pd2 = |s|^2, r = the 63rd-smallest pd2 (rd: its RDiv).
 template <int KIND>
-__device__ inline void photon_term_s(double sx, double sy, double sz, const uint4 &rr, const V3 &nrm, double pd2, double r,
+__device__ inline void photon_term_s(double sx, double sy, double sz, const uint4 &rr, const V3 &nrm, double pd2, const RDiv &rd,
                                      double &tr, double &tg, double &tb) {
     tr = tg = tb = 0.0;
     float pdx = __uint_as_float(rr.x), pdy = __uint_as_float(rr.y), pdz = __uint_as_float(rr.z);
     double d = -(nrm.x * (double)pdx + nrm.y * (double)pdy + nrm.z * (double)pdz);
     if (d <= 0) return;
-    // the plane filter with its dist.z quirk: NaN compares false -> photon kept
-    double k = (sx * nrm.x + sy * nrm.y + sz * nrm.z) / (sz * sz + sz * sz + sz * sz);
-    sx *= k; sy *= k; sz *= k;
-    if (sx * sx + sy * sy + sz * sz > 0.1) return;
-    double filter = (1 - pd2 / r);
+    // The plane filter with its dist.z quirk: s is scaled by k = (s . n) / (3 s_z^2) and the photon dropped
+    // when |k s|^2 > 0.1; NaN compares false -> photon kept.  Only the verdict is used.  In real numbers |k s|^2 =
+    // num^2 |s|^2 / den^2; the reference's rounded value is within a few 2^-53 of that (relative) whenever nothing
+    // overflows, is infinite or NaN, so a comparison of num^2 |s|^2 with 0.1 den^2 that clears a 2^-30 band settles it
+    // without the division; inside the band, and for every unusual operand, the reference's own arithmetic decides.
+    const double num = sx * nrm.x + sy * nrm.y + sz * nrm.z, den = sz * sz + sz * sz + sz * sz;
+    const double A = num * num * pd2, B = den * den;
+    const bool usual = den >= 0x1p-300 && B <= 0x1p600 && A <= 0x1p600;
+    const bool far = usual && A > B * (0.1 * (1.0 + 0x1p-30)), near = usual && A < B * (0.1 * (1.0 - 0x1p-30));
+    if (far) return;
+    if (!near) {
+        const double k = num / den;
+        sx *= k; sy *= k; sz *= k;
+        if (sx * sx + sy * sy + sz * sz > 0.1) return;
+    }
+    double filter = (1 - rdiv(rd, pd2));
     uint32_t pw = rr.w;
     int p0 = pw & 0xFF, p1 = (pw >> 8) & 0xFF, p2 = (pw >> 16) & 0xFF;
     if (KIND == 0) {
@@ -297,7 +331,7 @@ __device__ inline void photon_term_s(double sx, double sy, double sz, const uint
 template <int KIND>
 __device__ inline void photon_term(const float4 &pp, const uint4 &rr, const V3 &p, const V3 &nrm, double pd2, double r,
                                    double &tr, double &tg, double &tb) {
-    photon_term_s<KIND>(p.x - (double)pp.x, p.y - (double)pp.y, p.z - (double)pp.z, rr, nrm, pd2, r, tr, tg, tb);
+    photon_term_s<KIND>(p.x - (double)pp.x, p.y - (double)pp.y, p.z - (double)pp.z, rr, nrm, pd2, rdiv_make(r), tr, tg, tb);
 }
 
 constexpr double FX_SCALE = 72057594037927936.0;   // 2^56
@@ -305,10 +339,10 @@ constexpr double FX_SCALE = 72057594037927936.0;   // 2^56
 // The same term as its three addends of the canonical sum: trunc(term * 2^56), per channel.  For the caustic map the three
 // channels are one value or nothing (the power factor is 0 or 1), so it is converted once.
 template <int KIND>
-__device__ inline void photon_term_fx(double sx, double sy, double sz, const uint4 &rr, const V3 &nrm, double pd2, double r,
+__device__ inline void photon_term_fx(double sx, double sy, double sz, const uint4 &rr, const V3 &nrm, double pd2, const RDiv &rd,
                                       long long &fr, long long &fg, long long &fb) {
     double tr, tg, tb;
-    photon_term_s<KIND>(sx, sy, sz, rr, nrm, pd2, r, tr, tg, tb);
+    photon_term_s<KIND>(sx, sy, sz, rr, nrm, pd2, rd, tr, tg, tb);
     if (KIND == 0) {
         fr = (long long)(tr * FX_SCALE); fg = (long long)(tg * FX_SCALE); fb = (long long)(tb * FX_SCALE);
     } else {
@@ -340,6 +374,7 @@ __device__ inline void knn_gather(KnnBuf *buf, const MapView &m, const V3 &p, co
     if (found == 0) return;
     if (st.lane < 3) buf->acc[st.lane] = 0ULL;
     wave_lds_fence();
+    const RDiv rd = rdiv_make(r);
     if (st.lane < found) {
         double d2 = __longlong_as_double((long long)buf->d[st.lane]);
         if (d2 < r) {   // d2 == r has weight 0
@@ -347,7 +382,7 @@ __device__ inline void knn_gather(KnnBuf *buf, const MapView &m, const V3 &p, co
             float4 pp = m.pos4[i];
             uint4 rr = m.rest[i];
             long long fr, fg, fb;
-            photon_term_fx<KIND>(p.x - (double)pp.x, p.y - (double)pp.y, p.z - (double)pp.z, rr, nrm, d2, r, fr, fg, fb);
+            photon_term_fx<KIND>(p.x - (double)pp.x, p.y - (double)pp.y, p.z - (double)pp.z, rr, nrm, d2, rd, fr, fg, fb);
             // canonical order-independent sum: 64-bit fixed point in LDS
             if (fr != 0) atomicAdd(&buf->acc[0], (unsigned long long)fr);
             if (fg != 0) atomicAdd(&buf->acc[1], (unsigned long long)fg);

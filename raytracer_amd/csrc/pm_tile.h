@@ -369,6 +369,7 @@ __device__ inline bool tile_gather(TileBuf *tb, const Strip &S, const MapView &m
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) mcm = max(mcm, __shfl_xor(mcm, s));
     long long aR = 0, aG = 0, aB = 0;
+    const RDiv rd = rdiv_make(r);
     // three stages in flight: photon index of members k+4, k+5; the two records of members k+2, k+3; the terms of k, k+1
     auto index_of = [&](int k) -> uint32_t { return k < mc ? S.idx[sel.member[lane * TS_MROW + k]] : 0u; };
     auto term = [&](int k, const float4 &s, const uint4 &rr) {
@@ -376,7 +377,7 @@ __device__ inline bool tile_gather(TileBuf *tb, const Strip &S, const MapView &m
             long long fr, fg, fb;
             // d2 as everywhere (photon - point, three squares summed left to right); the term wants point - photon: the negation is exact
             const double ddx = (double)s.x - p.x, ddy = (double)s.y - p.y, ddz = (double)s.z - p.z;
-            photon_term_fx<KIND>(-ddx, -ddy, -ddz, rr, nrm, ddx * ddx + ddy * ddy + ddz * ddz, r, fr, fg, fb);
+            photon_term_fx<KIND>(-ddx, -ddy, -ddz, rr, nrm, ddx * ddx + ddy * ddy + ddz * ddz, rd, fr, fg, fb);
             aR += fr; aG += fg; aB += fb;
         }
     };
