@@ -301,16 +301,20 @@ __device__ inline void photon_term_s(double sx, double sy, double sz, const uint
     // num^2 |s|^2 / den^2; the reference's rounded value is within a few 2^-53 of that (relative) whenever nothing
     // overflows, is infinite or NaN, so a comparison of num^2 |s|^2 with 0.1 den^2 that clears a 2^-30 band settles it
     // without the division; inside the band, and for every unusual operand, the reference's own arithmetic decides.
+    // One unusual operand is common: s_z == 0 exactly (a shade point on the back wall and a photon on it, both at z = 10).
+    // Then k is a NaN or an infinity, k s_z is a NaN either way and so is the sum: the photon is kept.
     const double num = sx * nrm.x + sy * nrm.y + sz * nrm.z, den = sz * sz + sz * sz + sz * sz;
     const double A = num * num * pd2, B = den * den;
-    const bool usual = den >= 0x1p-300 && B <= 0x1p600 && A <= 0x1p600;
-    const bool far = usual && A > B * (0.1 * (1.0 + 0x1p-30)), near = usual && A < B * (0.1 * (1.0 - 0x1p-30));
-    if (far) return;
-    if (!near) {
+    // (bitwise, not short-circuit: one rare branch instead of a ladder of them)
+    const bool usual = (den >= 0x1p-300) & (B <= 0x1p600) & (A <= 0x1p600);
+    const bool keep = (sz == 0.0) | (usual & (A < B * (0.1 * (1.0 - 0x1p-30))));
+    bool drop = usual & (A > B * (0.1 * (1.0 + 0x1p-30)));
+    if (__builtin_expect(!(keep | drop), 0)) {
         const double k = num / den;
-        sx *= k; sy *= k; sz *= k;
-        if (sx * sx + sy * sy + sz * sz > 0.1) return;
+        const double kx = sx * k, ky = sy * k, kz = sz * k;
+        drop = kx * kx + ky * ky + kz * kz > 0.1;
     }
+    if (drop) return;
     double filter = (1 - rdiv(rd, pd2));
     uint32_t pw = rr.w;
     int p0 = pw & 0xFF, p1 = (pw >> 8) & 0xFF, p2 = (pw >> 16) & 0xFF;
