@@ -298,16 +298,18 @@ __device__ inline void photon_term_s(double sx, double sy, double sz, const uint
     if (d <= 0) return;
     // The plane filter with its dist.z quirk: s is scaled by k = (s . n) / (3 s_z^2) and the photon dropped
     // when |k s|^2 > 0.1; NaN compares false -> photon kept.  Only the verdict is used.  In real numbers |k s|^2 =
-    // num^2 |s|^2 / den^2; the reference's rounded value is within a few 2^-53 of that (relative) whenever nothing
-    // overflows, is infinite or NaN, so a comparison of num^2 |s|^2 with 0.1 den^2 that clears a 2^-30 band settles it
-    // without the division; inside the band, and for every unusual operand, the reference's own arithmetic decides.
-    // One unusual operand is common: s_z == 0 exactly (a shade point on the back wall and a photon on it, both at z = 10).
-    // Then k is a NaN or an infinity, k s_z is a NaN either way and so is the sum: the photon is kept.
+    // num^2 |s|^2 / den^2, and the reference's rounded value is within a few 2^-53 of that (relative) as long as no
+    // intermediate overflows, underflows, is infinite or NaN; so is the comparison of A = num^2 |s|^2 with 0.1 B, B = den^2,
+    // when num^2, A and B are normal numbers (`usual`: the bounds below keep every product in range).  A verdict that
+    // clears a 2^-30 band is therefore the reference's, without the division; inside the band, and for every unusual
+    // operand, the reference's own arithmetic decides.  Two unusual operands are common and settled by rule:
+    //   s_z == 0 exactly (shade point and photon both on the back wall): k is a NaN or an infinity, k s_z a NaN: kept;
+    //   num == 0 exactly (shade point and photon on the same axis-aligned wall): k is a zero or a NaN, and so is k s: kept.
     const double num = sx * nrm.x + sy * nrm.y + sz * nrm.z, den = sz * sz + sz * sz + sz * sz;
-    const double A = num * num * pd2, B = den * den;
+    const double m = num * num, A = m * pd2, B = den * den;
     // (bitwise, not short-circuit: one rare branch instead of a ladder of them)
-    const bool usual = (den >= 0x1p-300) & (B <= 0x1p600) & (A <= 0x1p600);
-    const bool keep = (sz == 0.0) | (usual & (A < B * (0.1 * (1.0 - 0x1p-30))));
+    const bool usual = (den >= 0x1p-300) & (B <= 0x1p600) & (m >= 0x1p-500) & (A >= 0x1p-960) & (A <= 0x1p600);
+    const bool keep = (sz == 0.0) | (num == 0.0) | (usual & (A < B * (0.1 * (1.0 - 0x1p-30))));
     bool drop = usual & (A > B * (0.1 * (1.0 + 0x1p-30)));
     if (__builtin_expect(!(keep | drop), 0)) {
         const double k = num / den;

@@ -103,3 +103,51 @@ def test_other_cameras_and_light_colours(gpu_ctx, orc, cam, lc):
     assert np.array_equal(pane, want)
     assert (st.closest_hit_queries, st.shadow_queries, st.gathers) == (ost.closest_hit_queries, ost.shadow_queries, ost.gathers)
     g.destroy(); c.destroy(); og.close(); oc.close()
+
+
+def test_plane_filter_verdicts_on_adversarial_operands(gpu_ctx, orc):
+    """The radiance sum settles the reference's plane filter |k s|^2 > 0.1 (src/Raytrace.cpp:108-113) without its division
+    when the verdict is clear and by the reference's own arithmetic otherwise (pm_knn.h).  Here the operands are made
+    awkward on purpose: s_z and s . n exactly zero, tiny and huge ratios, normals from 1e-200 to 1 in length, and normals
+    scaled so that |k s|^2 lands within 2^-33 .. 2^-27 of 0.1 on either side, or on it.  Bits must equal the oracle's."""
+    import raytracer_amd as ra
+    rng = np.random.default_rng(77)
+    n_ph = 6000
+    ph = np.zeros(n_ph, dtype=ra.photon_dtype)
+    pos = rng.uniform(-1.0, 1.0, (n_ph, 3)).astype(np.float32)
+    pos[::5, 2] = 0.0                                   # a plane of photons at z = 0 exactly
+    pos[1::7, 1] = 0.25                                 # and one at y = 0.25
+    ph["x"], ph["y"], ph["z"] = pos[:, 0], pos[:, 1], pos[:, 2]
+    d = rng.normal(size=(n_ph, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ph["dx"], ph["dy"], ph["dz"] = d[:, 0].astype(np.float32), d[:, 1].astype(np.float32), d[:, 2].astype(np.float32)
+    ph["power"] = rng.integers(0, 256, (n_ph, 4), dtype=np.uint8)
+    for kind in (0, 1):
+        gm, om = gpu_ctx.build_map(ph, kind), orc.Map(ph)
+        pts, nrm = [], []
+        for q in range(600):
+            p = rng.uniform(-0.9, 0.9, 3)
+            mode = q % 6
+            if mode == 0: p[2] = 0.0                                         # s_z == 0 against the z = 0 photons
+            if mode == 1: p[2] = 10.0 ** -rng.integers(20, 300)              # s_z tiny: den underflows or is denormal
+            if mode == 2: p[1] = 0.25                                        # s . n == 0 with n = (0, 1, 0) below
+            n = rng.normal(size=3); n /= np.linalg.norm(n)
+            if mode == 2: n = np.array([0.0, 1.0, 0.0])
+            if mode == 3: n *= 10.0 ** -rng.integers(1, 201)                 # num^2 from ordinary to far below 2^-500
+            if mode >= 4:
+                # aim at the threshold: pick one of the query's own neighbours and scale n so that, for it, the filter's
+                # value is 0.1 (1 + delta)
+                f, idx, d2 = om.knn_exact(p)
+                j = idx[rng.integers(0, max(f - 1, 1))]
+                s = p - np.array([ph["x"][j], ph["y"][j], ph["z"][j]], dtype=np.float64)
+                den = 3.0 * s[2] * s[2]
+                t1 = (np.dot(s, n) / den) ** 2 * np.dot(s, s) if den > 0 else 0.0
+                if t1 > 0.1:
+                    delta = rng.choice([0.0, 2.0 ** -33, -2.0 ** -33, 2.0 ** -31, -2.0 ** -31, 2.0 ** -29, -2.0 ** -29, 2.0 ** -27, -2.0 ** -27, 1e-15, -1e-15])
+                    n *= np.sqrt(0.1 * (1.0 + delta) / t1)
+            pts.append(p); nrm.append(n)
+        pts, nrm = np.array(pts), np.array(nrm)
+        rad = gpu_ctx.knn_gather(gm, pts, nrm)
+        want = om.gather(kind, pts, nrm, order=orc.ORDER_CANONICAL)
+        assert np.array_equal(rad.view(np.uint64), want.view(np.uint64))
+        assert np.isfinite(want).all() and (want > 0).any()
+        gm.destroy(); om.close()
