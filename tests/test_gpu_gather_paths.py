@@ -172,3 +172,17 @@ def test_config3_size_group_gather_equals_per_query_gather(monkeypatch):
             ctx.close()
     assert np.array_equal(panes[0], panes[1])
     assert len(np.unique(panes[0])) > 1000
+
+
+def test_config3_size_rows_equal_the_oracle():
+    """BASELINE config 3's sizes again, against the oracle itself: the oracle cannot render 33 million pixels in a test, but
+    it can render every 16th row of them on the same 2 x 10M photons (bench.py --check does exactly that: GPU maps
+    downloaded, oracle index on them, 270 rows, 25 million rays, 1.9 million gathers).  Those rows are bit-identical."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--width", "7680", "--height", "4320",
+                        "--photons", "10000000", "--cpu-row-stride", "16", "--check"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["cpu_baseline"]["sample_rows_bit_identical_to_gpu"] is True
+    assert "270 rows" in j["cpu_baseline"]["sample"]
