@@ -33,17 +33,24 @@ WORKLOAD = {"default": "default Cornell scene", "spheres10k": "five walls + 10,0
             "caustics": "five walls + five glass spheres (BASELINE config 4 scene),"}
 
 
+def latest_pmc_summary():
+    """profiles/rNN/pmc_per_dispatch_avg.json of the latest round that has one."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", "pmc_per_dispatch_avg.json")))
+    return found[-1] if found else os.path.join(ROOT, "profiles", "r01", "pmc_per_dispatch_avg.json")
+
+
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed PMC passes of this same command (tools/profile_bench.sh:
     FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs; rocprofv3 reports KB; gfx950 correction: FETCH_SIZE tallies the
     128-byte read requests at 64 bytes, so it is doubled -- MI355X_MICROARCH.md, HBM section)."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_per_dispatch_avg.json")
+    path = latest_pmc_summary()
     try:
         with open(path) as f:
             pmc = json.load(f)
         for name, c in pmc.items():
             if kernel in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, "2 x FETCH_SIZE + WRITE_SIZE of profiles/r01/pmc_per_dispatch_avg.json (not collected live)"
+                return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, f"2 x FETCH_SIZE + WRITE_SIZE of {os.path.relpath(path, ROOT)} (not collected live)"
     except (OSError, ValueError):
         pass
     return None, "no PMC summary found"
@@ -57,7 +64,7 @@ def pmc_valu_issue(kernel, launch_ms):
     """What actually bounds the gather kernels: vector instructions issued per second, from the
     committed SQ_INSTS_VALU count of one launch of `kernel` over the launch time measured live, against the measured
     issue rate of the whole device.  The other map's kernel shares the device during that time."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_per_dispatch_avg.json")
+    path = latest_pmc_summary()
     try:
         with open(path) as f:
             pmc = json.load(f)
@@ -65,7 +72,7 @@ def pmc_valu_issue(kernel, launch_ms):
             if kernel in name and "SQ_INSTS_VALU" in c and launch_ms > 0:
                 ach = c["SQ_INSTS_VALU"] / (launch_ms * 1e-3) / 1e9
                 return {"achieved": ach, "peak": VALU_PEAK_GINSTR_S, "unit": "G wave-instr/s", "frac": ach / VALU_PEAK_GINSTR_S,
-                        "note": "SQ_INSTS_VALU per launch from profiles/r01/pmc_per_dispatch_avg.json (default scene; not collected live) "
+                        "note": f"SQ_INSTS_VALU per launch from {os.path.relpath(path, ROOT)} (default scene; not collected live) "
                                 "/ live launch time; peak = 1024 SIMDs x one FP64 instruction per 2.2 ns (profiles/r01/valu_rates.txt); "
                                 "the two maps' kernels run side by side, each taking its share of that peak"}
     except (OSError, ValueError):
