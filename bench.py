@@ -104,6 +104,10 @@ def cpu_baseline(frame, args, cores, scene):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--maps", default="auto", choices=["auto", "allgather", "replicate"],
+                    help="with more than one rank: emission split by attempt range + one all-gather of the shards (the path as specified), "
+                         "or every rank emits every map itself and nothing is exchanged (same maps, bit for bit); auto times a few "
+                         "untimed steps of each before the warmup and keeps the faster (all ranks agree on the slowest rank's times)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--width", type=int, default=1440)
@@ -141,23 +145,46 @@ def main():
     torch.cuda.set_device(local_rank)
     # PM_FORCE_DIST=1 (tests): take the collective path even with one rank, to exercise RCCL on device buffers
     use_dist = world > 1 or os.environ.get("PM_FORCE_DIST") == "1"
+    # The library's context first: a process has 4 hardware queues and streams are dealt onto them in the order they are
+    # created.  Created after RCCL's, the library's three streams end up sharing queues and the gathers that are meant to
+    # run side by side run one behind the other (measured with one rank: 3.8 - 4.1 ms per step instead of 3.0).
+    ctx = ra.Context(local_rank)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    ctx = ra.Context(local_rank)
     scene = {"default": ra.default_scene, "spheres10k": ra.many_spheres_scene, "caustics": ra.caustics_scene}[args.scene]()
     ctx.upload_scene(scene)                   # the input that is resident before the timed region
     frame = GpuFrame(ctx, args.width, args.height, args.photons, args.seed, rank=rank, world=world,
-                     dist=dist if use_dist else None)
+                     dist=dist if use_dist else None, replicate_maps=args.maps == "replicate")
+    maps_mode, maps_tune = args.maps, None
 
     def sync():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if use_dist and args.maps == "auto":
+        # which way of making the maps is faster HERE (ranks, links, photon count): a few untimed steps of each
+        maps_tune = {}
+        for mode in ("allgather", "replicate"):
+            frame.replicate_maps = mode == "replicate"
+            for _ in range(2):
+                frame.step()
+            sync()
+            ta = time.perf_counter()
+            for _ in range(5):
+                frame.step()
+            sync()
+            tm = torch.tensor([time.perf_counter() - ta], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            maps_tune[mode] = float(tm[0]) / 5 * 1e3
+        maps_mode = min(maps_tune, key=maps_tune.get)
+        frame.replicate_maps = maps_mode == "replicate"
+    elif not use_dist:
+        maps_mode = "local"
     for _ in range(args.warmup):
         frame.step()
     sync()
@@ -205,7 +232,9 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{WORKLOAD[args.scene]} {args.width}x{args.height}, 1 spp, {args.photons} global + {args.photons} caustic photons, "
                                    f"k=63, 25 shadow rays, depth<=3{' (BASELINE config 2)' if args.scene == 'default' else ''}; step = emit both maps + build indices + trace/shade + pane on rank 0",
-                       "seed": args.seed, "parallelism": f"rows x{world} (16-row blocks), emission attempts x{world} + all-gather"},
+                       "seed": args.seed, "parallelism": f"rows x{world} (16-row blocks), " + (f"emission attempts x{world} + all-gather" if maps_mode == "allgather" else
+                                                                                   "every map emitted on every rank, no exchange" if maps_mode == "replicate" else "one rank"),
+                       "maps_autotune_ms_per_step": maps_tune},
             "gathers_per_s": gathers / step_s, "frame_time_s": step_s, "rays_per_frame": rays, "gathers_per_frame": gathers,
             "phases_ms_rank0": {**{k: v / args.steps for k, v in phase.items()}, "maps_enqueue_host_wall": t_maps / args.steps * 1e3},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -91,7 +91,9 @@ typedef struct pm_stats {
     uint32_t grouped_global, grouped_caustic;
 } pm_stats;
 
-/* scheduler::startWorkers(int), src/JobSystem.cpp:76-86 (called at src/Main.cpp:34): `device` takes the place of `cores`. */
+/* scheduler::startWorkers(int), src/JobSystem.cpp:76-86 (called at src/Main.cpp:34): `device` takes the place of `cores`.
+ * The context creates three streams of its own.  In a process that also uses RCCL, create the context first: hardware
+ * queues (4 per process) are dealt to streams in creation order, and streams that share one run one behind the other. */
 int pm_ctx_create(int device, pm_ctx **out);
 int pm_ctx_destroy(pm_ctx *ctx);
 /* Issue all work on this hipStream_t (NULL = the null stream). */

@@ -106,7 +106,7 @@ class GpuFrame:
     """renderScene on one rank of a (possibly single-rank) job; all compute through the HIP library."""
 
     def __init__(self, ctx, width, height, n_photons, seed, rank=0, world=1, dist=None,
-                 cam=(0.0, 0.0, -12.0), light_color=(0.6, 0.6, 0.6), flags=0):
+                 cam=(0.0, 0.0, -12.0), light_color=(0.6, 0.6, 0.6), flags=0, replicate_maps=False):
         import torch
         self.torch, self.ctx, self.dist = torch, ctx, dist
         self.w, self.h, self.n, self.seed = width, height, n_photons, seed
@@ -119,6 +119,10 @@ class GpuFrame:
         self._shard_bufs = {}       # kind -> (own shard, all shards), device byte tensors reused across frames
         self._fast_shards = dist is not None and hasattr(dist, "all_gather_into_tensor")
         self._yields = None         # stored photons per attempt in THIS scene, probed once (every rank finds the same numbers)
+        # Every rank emits every map itself and nothing is exchanged (the random streams are counter-based: all ranks get the
+        # same maps).  Not the default: the path as specified splits the emission and all-gathers the shards.  Which of the
+        # two is faster depends on what the all-gather sustains against 5 G photons/s of emission per GPU.
+        self.replicate_maps = replicate_maps
 
     # --- photon maps: createPhotonMap / createCausticPhotonMap, src/Raytrace.cpp:314-316
     def _emit_fn(self, kind):
@@ -180,7 +184,7 @@ class GpuFrame:
         for kind in (1, 0):   # the caustic map takes longer (more attempts per photon): its build goes first
             if self.flags & (1 << kind):
                 continue
-            if self.dist is None:
+            if self.dist is None or self.replicate_maps:
                 self.maps[kind] = self.ctx.create_map(kind, self.n, self.seed, self.light_color, wait=False)
             elif fast and self._fast_shards:
                 self.maps[kind] = self._build_map_from_shards(kind)

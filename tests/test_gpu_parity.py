@@ -165,20 +165,23 @@ def test_full_frame_bit_exact_vs_oracle_and_rank_split(gpu_ctx, orc):
     gm.destroy(); cm.destroy(); og.close(); oc.close()
 
 
-def test_bench_collective_path_on_one_rank(tmp_path, orc):
-    """bench.py through its distributed code path (RCCL all_gather of device photon shards, gather of row
-    blocks) with a one-rank process group: same pane as the oracle."""
+@pytest.mark.parametrize("maps", ["auto", "allgather", "replicate"])
+def test_bench_collective_path_on_one_rank(tmp_path, orc, maps):
+    """bench.py through its distributed code path (RCCL all_gather of device photon shards -- or, with --maps replicate,
+    every map emitted locally -- and the gather of row blocks) with a one-rank process group: same pane as the oracle."""
     import os, subprocess, sys, json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = tmp_path / "pane.bin"
     env = dict(os.environ, PM_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--width", "320", "--height", "200",
-                        "--photons", "20000", "--seed", "77", "--no-cpu-baseline", "--dump-pane", str(out)],
+                        "--photons", "20000", "--seed", "77", "--no-cpu-baseline", "--maps", maps, "--dump-pane", str(out)],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["roofline"]["achieved"] > 0
+    tune = j["config"]["maps_autotune_ms_per_step"]
+    assert (set(tune) == {"allgather", "replicate"}) if maps == "auto" else tune is None
     pane = np.fromfile(out, dtype=np.uint32).reshape(200, 320)
     scene = orc.default_scene()
     g, c = orc.Map(orc.emit(scene, 0, 77, 20000)[0]), orc.Map(orc.emit(scene, 1, 77, 20000)[0])
