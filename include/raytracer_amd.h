@@ -113,6 +113,16 @@ int pm_emit_range(pm_ctx *ctx, int32_t map_kind, uint64_t seed, const double lig
                   uint64_t attempt_begin, uint64_t attempt_count, pm_photon *d_out, uint64_t cap,
                   uint64_t *out_count);
 
+/* pm_emit_range without any allocation.  No counterpart in the reference: it is for callers that cannot call hipMalloc
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid it).  Same arguments, same records and count
+ * as pm_emit_range, bit for bit; the kernels' scratch (attempt records, flags, block counts and offsets, 4.4 MB) is a
+ * static device array that every GPU the library runs on holds until the process ends, so attempt_count is limited to
+ * PM_EMIT_STATIC_MAX_ATTEMPTS (more: PM_EINVAL).  Calls on one GPU share that array: calls that overlap on one GPU race. */
+#define PM_EMIT_STATIC_MAX_ATTEMPTS 131072
+int pm_emit_range_static(pm_ctx *ctx, int32_t map_kind, uint64_t seed, const double light_color[3],
+                         uint64_t attempt_begin, uint64_t attempt_count, pm_photon *d_out, uint64_t cap,
+                         uint64_t *out_count);
+
 /* pm_emit_range for one rank of a multi-GPU job, without a wait: the shard is DEVICE memory of 32 + 32 * cap bytes, a
  * 32-byte header {uint64 count, uint64 cap, 0, 0} followed by the first cap successes of the range in attempt order.
  * count = successes in the range (it may exceed cap).  Everything is queued on the context's stream; the shards of all

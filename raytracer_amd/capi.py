@@ -14,6 +14,7 @@ PM_MAP_GLOBAL, PM_MAP_CAUSTIC = 0, 1
 PM_FLAG_NO_GLOBAL, PM_FLAG_NO_CAUSTIC, PM_FLAG_NO_DIRECT = 1, 2, 4
 PM_K = 63
 PM_ROW_BLOCK = 16
+PM_EMIT_STATIC_MAX_ATTEMPTS = 131072
 
 # pm_prim / pm_photon as numpy structured dtypes (layouts identical to the C structs)
 prim_dtype = np.dtype([
@@ -51,7 +52,7 @@ class PMError(RuntimeError):
 
 
 EXPORTS = ["pm_ctx_create", "pm_ctx_destroy", "pm_ctx_set_stream", "pm_last_error", "pm_scene_upload",
-           "pm_emit_range", "pm_emit_shard", "pm_map_build", "pm_map_build_shards", "pm_map_create", "pm_map_size", "pm_map_download", "pm_map_destroy",
+           "pm_emit_range", "pm_emit_range_static", "pm_emit_shard", "pm_map_build", "pm_map_build_shards", "pm_map_create", "pm_map_size", "pm_map_download", "pm_map_destroy",
            "pm_knn_query", "pm_knn_profile", "pm_knn_gather", "pm_primary_hits", "pm_render"]
 
 _lib = None
@@ -67,6 +68,14 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own copy of the HIP runtime (torch/lib/libamdhip64.so) and this library is linked against
+    # ROCm's: whichever is loaded first serves the process, and a second runtime initialised beside it sees no GPU
+    # ("No HIP GPUs are available").  Where torch is installed it therefore goes first (the loader then binds this library to
+    # torch's copy by soname); without torch the library runs on ROCm's runtime alone.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = library_path()
     if not os.path.exists(path):
         raise PMError(f"{path} is missing: build it with `make -C raytracer_amd/csrc` (hipcc, gfx950); there is no CPU fallback")
@@ -76,6 +85,7 @@ def load_library():
         "pm_ctx_create": [C.c_int, C.POINTER(vp)], "pm_ctx_destroy": [vp], "pm_ctx_set_stream": [vp, vp],
         "pm_scene_upload": [vp, vp, i32],
         "pm_emit_range": [vp, i32, u64, C.POINTER(C.c_double), u64, u64, vp, u64, C.POINTER(u64)],
+        "pm_emit_range_static": [vp, i32, u64, C.POINTER(C.c_double), u64, u64, vp, u64, C.POINTER(u64)],
         "pm_map_build": [vp, vp, i64, i32, C.POINTER(vp)],
         "pm_map_create": [vp, i32, i64, u64, C.POINTER(C.c_double), C.POINTER(vp), C.POINTER(u64)],
         "pm_emit_shard": [vp, i32, u64, C.POINTER(C.c_double), u64, u64, vp, u64],
@@ -181,6 +191,13 @@ class Context:
         cnt = C.c_uint64()
         _check(self.lib.pm_emit_range(self.handle, kind, seed, _vec3(light_color), attempt_begin, attempt_count,
                                       C.c_void_p(d_out_ptr), cap, C.byref(cnt)))
+        return cnt.value
+
+    def emit_range_static(self, kind, seed, light_color, attempt_begin, attempt_count, d_out_ptr, cap):
+        """emit_range on the library's static scratch array: allocates nothing, at most PM_EMIT_STATIC_MAX_ATTEMPTS attempts."""
+        cnt = C.c_uint64()
+        _check(self.lib.pm_emit_range_static(self.handle, kind, seed, _vec3(light_color), attempt_begin, attempt_count,
+                                             C.c_void_p(d_out_ptr), cap, C.byref(cnt)))
         return cnt.value
 
     def emit_shard(self, kind, seed, light_color, attempt_begin, attempt_count, d_shard_ptr, cap):

@@ -47,6 +47,19 @@ struct DevBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// ---- scratch of pm_emit_range_static, the one entry point that allocates nothing: a file-scope device array (every GPU
+// the library runs on holds its own copy until the process ends).  Host code never uses the array's name as an address:
+// pm_ctx_create asks the runtime for the device address (hipGetSymbolAddress, with that device current) and keeps it
+// in the context; kernels get that pointer as an argument, exactly as they get the slot buffers in pm_emit_range.
+constexpr uint64_t ES_MAX = PM_EMIT_STATIC_MAX_ATTEMPTS;
+constexpr size_t es_align(size_t b) { return (b + 255) & ~(size_t)255; }
+constexpr size_t ES_OFF_TMP = 0;                                                   // ES_MAX records of 32 bytes (k_emit)
+constexpr size_t ES_OFF_FLAG = ES_OFF_TMP + es_align(ES_MAX * sizeof(pm_photon));  // one byte per attempt
+constexpr size_t ES_OFF_COUNTS = ES_OFF_FLAG + es_align(ES_MAX);                   // successes per block of 256 attempts
+constexpr size_t ES_OFF_OFFS = ES_OFF_COUNTS + es_align((ES_MAX / 256) * 4);       // their exclusive scan + the total
+constexpr size_t ES_BYTES = ES_OFF_OFFS + es_align((ES_MAX / 256 + 1) * 8);
+static __device__ __align__(256) unsigned char scratch[ES_BYTES];
+
 constexpr size_t LDS_SCENE_MAX = 48 * 1024;   // scenes up to this size are staged in LDS; larger ones are read from global memory
 constexpr int N_EVENTS = 8;
 
@@ -61,6 +74,7 @@ struct BuildSlot {
 
 struct pm_ctx {
     int device = 0;
+    unsigned char *static_scratch = nullptr;   // device address of `scratch` on this context's GPU (hipGetSymbolAddress)
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;           // the caustic gather runs beside the global one
     hipStream_t aux2 = nullptr;          // and the per-query gather of the bounced pixels' shade points beside both
@@ -117,6 +131,25 @@ static int set_device(pm_ctx *ctx) { HIPCHK(hipSetDevice(ctx->device)); return P
 
 extern "C" const char *pm_last_error(void) { return g_err.c_str(); }
 
+static int ctx_init(pm_ctx *ctx) {
+    HIPCHK(hipHostMalloc((void **)&ctx->h_ctr, sizeof(Counters), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&ctx->h_u64, 4 * sizeof(uint64_t), hipHostMallocDefault));
+    for (int i = 0; i < N_EVENTS; i++) HIPCHK(hipEventCreate(&ctx->ev[i]));
+    // two streams beside the caller's: more would share hardware queues (4 per process) and serialise behind each other.
+    // They carry the map builds, and later in the frame the caustic gather and the bounced pixels' gathers.
+    for (int i = 0; i < 2; i++) HIPCHK(hipStreamCreateWithFlags(&ctx->slot[i].stream, hipStreamNonBlocking));
+    ctx->aux = ctx->slot[0].stream; ctx->aux2 = ctx->slot[1].stream;
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    for (int k = 0; k < 2; k++) for (int i = 0; i < 3; i++) HIPCHK(hipEventCreate(&ctx->ev_g[k][i]));
+    // this GPU's copy of the static scratch array (the device is current: pm_ctx_create set it)
+    HIPCHK(hipGetSymbolAddress((void **)&ctx->static_scratch, HIP_SYMBOL(scratch)));
+    if (!ctx->static_scratch) return fail(PM_EHIP, "hipGetSymbolAddress(scratch) returned NULL");
+    return PM_OK;
+}
+
 extern "C" int pm_ctx_create(int device, pm_ctx **out) {
     if (!out) return fail(PM_EINVAL, "pm_ctx_create: out is NULL");
     int ndev = 0;
@@ -130,18 +163,8 @@ extern "C" int pm_ctx_create(int device, pm_ctx **out) {
     pm_ctx *ctx = new (std::nothrow) pm_ctx();
     if (!ctx) return fail(PM_ENOMEM, "out of host memory");
     ctx->device = device;
-    HIPCHK(hipHostMalloc((void **)&ctx->h_ctr, sizeof(Counters), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void **)&ctx->h_u64, 4 * sizeof(uint64_t), hipHostMallocDefault));
-    for (int i = 0; i < N_EVENTS; i++) HIPCHK(hipEventCreate(&ctx->ev[i]));
-    // two streams beside the caller's: more would share hardware queues (4 per process) and serialise behind each other.
-    // They carry the map builds, and later in the frame the caustic gather and the bounced pixels' gathers.
-    for (int i = 0; i < 2; i++) HIPCHK(hipStreamCreateWithFlags(&ctx->slot[i].stream, hipStreamNonBlocking));
-    ctx->aux = ctx->slot[0].stream; ctx->aux2 = ctx->slot[1].stream;
-    HIPCHK(hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    for (int k = 0; k < 2; k++) for (int i = 0; i < 3; i++) HIPCHK(hipEventCreate(&ctx->ev_g[k][i]));
+    int rc = ctx_init(ctx);
+    if (rc != PM_OK) { std::string msg = g_err; pm_ctx_destroy(ctx); g_err = msg; return rc; }   // nothing of a half-made context is left behind
     *out = ctx;
     return PM_OK;
 }
@@ -358,28 +381,38 @@ extern "C" int pm_scene_upload(pm_ctx *ctx, const pm_prim *prims, int32_t n) {
 // attempts [a0, a0+count) -> first `cap` successes, in attempt order, into d_out, on the slot's stream with the slot's
 // scratch; the number of successes in the range lands in *h_got (pinned) when the stream gets there.
 // total != NULL: wait for it.
-static int emit_range(pm_ctx *ctx, BuildSlot &sl, int kind, uint64_t seed, const double lc[3], uint64_t a0, uint64_t count, pm_photon *d_out,
-                      uint64_t cap, uint64_t *h_got, uint64_t *total) {
-    if (count == 0) { *h_got = 0; if (total) *total = 0; return PM_OK; }
-    if (count > (1ULL << 31)) return fail(PM_EINVAL, "emit_range: at most 2^31 attempts per call");
+struct EmitScratch { pm_photon *tmp; uint8_t *flag; uint32_t *counts; uint64_t *offs; };
+static int slot_scratch(BuildSlot &sl, uint64_t count, EmitScratch &es) {
     uint32_t nb = (uint32_t)((count + 255) / 256);
     PMCHK(sl.emit_tmp.ensure(count * sizeof(pm_photon)));
     PMCHK(sl.emit_flag.ensure(count));
     PMCHK(sl.emit_counts.ensure((size_t)nb * 4));
     PMCHK(sl.emit_offs.ensure(((size_t)nb + 1) * 8));
+    es = {sl.emit_tmp.as<pm_photon>(), sl.emit_flag.as<uint8_t>(), sl.emit_counts.as<uint32_t>(), sl.emit_offs.as<uint64_t>()};
+    return PM_OK;
+}
+static int emit_range_on(pm_ctx *ctx, hipStream_t stream, const EmitScratch &es, int kind, uint64_t seed, const double lc[3], uint64_t a0, uint64_t count,
+                         pm_photon *d_out, uint64_t cap, uint64_t *h_got, uint64_t *total) {
+    uint32_t nb = (uint32_t)((count + 255) / 256);
     uint64_t K = stream_key(seed, kind == PM_MAP_GLOBAL ? KIND_EMIT_GLOBAL : KIND_EMIT_CAUSTIC);
     V3 light = {lc[0], lc[1], lc[2]};
-    LAUNCH_SCENE_ON(k_emit, dim3(nb), dim3(256), ctx, sl.stream, kind, K, light, a0, count, sl.emit_tmp.as<pm_photon>(), sl.emit_flag.as<uint8_t>(),
-                    sl.emit_counts.as<uint32_t>());
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, sl.stream, sl.emit_counts.as<uint32_t>(), sl.emit_offs.as<uint64_t>(), nb);
-    hipLaunchKernelGGL(k_emit_scatter, dim3(nb), dim3(256), 0, sl.stream, sl.emit_tmp.as<pm_photon>(), sl.emit_flag.as<uint8_t>(),
-                       sl.emit_offs.as<uint64_t>(), count, d_out, cap);
+    LAUNCH_SCENE_ON(k_emit, dim3(nb), dim3(256), ctx, stream, kind, K, light, a0, count, es.tmp, es.flag, es.counts);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, es.counts, es.offs, nb);
+    hipLaunchKernelGGL(k_emit_scatter, dim3(nb), dim3(256), 0, stream, es.tmp, es.flag, es.offs, count, d_out, cap);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(h_got, sl.emit_offs.as<uint64_t>() + nb, 8, hipMemcpyDeviceToHost, sl.stream));
+    HIPCHK(hipMemcpyAsync(h_got, es.offs + nb, 8, hipMemcpyDeviceToHost, stream));
     if (!total) return PM_OK;
-    HIPCHK(hipStreamSynchronize(sl.stream));
+    HIPCHK(hipStreamSynchronize(stream));
     *total = *h_got;
     return PM_OK;
+}
+static int emit_range(pm_ctx *ctx, BuildSlot &sl, int kind, uint64_t seed, const double lc[3], uint64_t a0, uint64_t count, pm_photon *d_out,
+                      uint64_t cap, uint64_t *h_got, uint64_t *total) {
+    if (count == 0) { *h_got = 0; if (total) *total = 0; return PM_OK; }
+    if (count > (1ULL << 31)) return fail(PM_EINVAL, "emit_range: at most 2^31 attempts per call");
+    EmitScratch es;
+    PMCHK(slot_scratch(sl, count, es));
+    return emit_range_on(ctx, sl.stream, es, kind, seed, lc, a0, count, d_out, cap, h_got, total);
 }
 
 extern "C" int pm_emit_range(pm_ctx *ctx, int32_t map_kind, uint64_t seed, const double light_color[3], uint64_t attempt_begin,
@@ -390,6 +423,27 @@ extern "C" int pm_emit_range(pm_ctx *ctx, int32_t map_kind, uint64_t seed, const
     PMCHK(set_device(ctx));
     ctx->slot[2].stream = ctx->stream;
     return emit_range(ctx, ctx->slot[2], map_kind, seed, light_color, attempt_begin, attempt_count, d_out, cap, ctx->h_u64, out_count);
+}
+
+// pm_emit_range for callers that cannot allocate (code under HIP graph capture, tight serving loops): the same kernels on
+// the static scratch array instead of the slot's hipMalloc'ed buffers.  No hipMalloc / hipFree / allocating routine is
+// called.  Every call on a GPU shares that GPU's array: a call overwrites all of the scratch it reads (flags, block counts,
+// offsets, records of its own attempts), so nothing has to be cleared, and two calls that overlap on one GPU race.
+extern "C" int pm_emit_range_static(pm_ctx *ctx, int32_t map_kind, uint64_t seed, const double light_color[3], uint64_t attempt_begin,
+                                    uint64_t attempt_count, pm_photon *d_out, uint64_t cap, uint64_t *out_count) {
+    if (!ctx || !light_color || !out_count || (!d_out && cap)) return fail(PM_EINVAL, "pm_emit_range_static: NULL argument");
+    if (map_kind != PM_MAP_GLOBAL && map_kind != PM_MAP_CAUSTIC) return fail(PM_EINVAL, "pm_emit_range_static: bad map_kind");
+    if (attempt_count > ES_MAX)
+        return fail(PM_EINVAL, "pm_emit_range_static: at most " + std::to_string(ES_MAX) + " attempts per call (PM_EMIT_STATIC_MAX_ATTEMPTS: the static scratch "
+                               "array holds no more); split the range, or use pm_emit_range");
+    if (ctx->nprims == 0) return fail(PM_ESTATE, "pm_emit_range_static: no scene uploaded");
+    if (!ctx->static_scratch) return fail(PM_ESTATE, "pm_emit_range_static: the context has no address for the static scratch array");
+    PMCHK(set_device(ctx));
+    if (attempt_count == 0) { *out_count = 0; return PM_OK; }
+    unsigned char *sp = ctx->static_scratch;   // the device address, never the array's name
+    const EmitScratch es = {reinterpret_cast<pm_photon *>(sp + ES_OFF_TMP), sp + ES_OFF_FLAG, reinterpret_cast<uint32_t *>(sp + ES_OFF_COUNTS),
+                            reinterpret_cast<uint64_t *>(sp + ES_OFF_OFFS)};
+    return emit_range_on(ctx, ctx->stream, es, map_kind, seed, light_color, attempt_begin, attempt_count, d_out, cap, ctx->h_u64, out_count);
 }
 
 extern "C" int pm_emit_shard(pm_ctx *ctx, int32_t map_kind, uint64_t seed, const double light_color[3], uint64_t attempt_begin,
