@@ -96,6 +96,9 @@ typedef struct pm_stats {
  * queues (4 per process) are dealt to streams in creation order, and streams that share one run one behind the other. */
 int pm_ctx_create(int device, pm_ctx **out);
 int pm_ctx_destroy(pm_ctx *ctx);
+/* scheduler::waitForCompletion(), src/JobSystem.cpp:109-118: returns when everything the context has queued (the caller's
+ * stream and the library's two build / gather streams) is done.  Unlike the reference's, the context stays usable. */
+int pm_ctx_synchronize(pm_ctx *ctx);
 /* Issue all work on this hipStream_t (NULL = the null stream). */
 int pm_ctx_set_stream(pm_ctx *ctx, void *hip_stream);
 const char *pm_last_error(void);
@@ -150,6 +153,10 @@ int pm_map_build(pm_ctx *ctx, const pm_photon *records, int64_t n, int32_t recor
 int pm_map_create(pm_ctx *ctx, int32_t map_kind, int64_t n, uint64_t seed, const double light_color[3],
                   pm_map **out, uint64_t *attempts_used);
 int pm_map_size(const pm_map *map, int64_t *n);
+/* The two phase times createPhotonMap prints (src/PhotonMap.cpp:369-371 "photons traced in", :378-382 "kd-tree built in"):
+ * device time of the map's emission and of its index build, from HIP events on the stream they ran on (ms).  Waits for the map.
+ * A map that had to be topped up synchronously reports the first, asynchronous part only. */
+int pm_map_times(pm_map *map, float *ms_emit, float *ms_build);
 /* Copies the n records, in emission order, to host memory. */
 int pm_map_download(pm_map *map, pm_photon *host_out);
 /* deleteTree, src/PhotonMap.cpp:504-513 */
@@ -176,12 +183,33 @@ int pm_knn_gather(pm_ctx *ctx, pm_map *map, int32_t map_kind, int64_t m, const d
 int pm_primary_hits(pm_ctx *ctx, const pm_render_params *rp, int32_t y0, int32_t y1, int32_t *ids,
                     double *points, double *normals);
 
+/* SceneObject::intersect (src/Scene.h:11; SphereObject src/Scene.cpp:87-116, PlaneObject :135-193) and Scene::intersect
+ * (src/Scene.h:32, src/Scene.cpp:25-47) for n caller-given rays, one lane per ray, through the device functions the frame
+ * kernels use.  Host arrays: src, dir n x 3 doubles (dir as given: not normalised here), dt n doubles (NULL = 0).
+ * prim[i] >= 0: that primitive alone; hit[i] = 1 / 0.  prim[i] < 0 or prim == NULL: closest hit over the scene, skipping
+ * exclude[i] (NULL = nothing); hit[i] = object id or -1.  res / nrm (n x 3 doubles) are written on a hit and left as they
+ * were on a miss, like the reference's out-parameters. */
+int pm_intersect_rays(pm_ctx *ctx, int64_t n, const double *src, const double *dir, const double *dt,
+                      const int32_t *prim, const int32_t *exclude, int32_t *hit, double *res, double *nrm);
+
 /* The submit loop + waitForCompletion of renderScene (src/Raytrace.cpp:322-336): traces this rank's
  * row blocks into `pane` (full width x height image, pane[x + y*width] = 0xAARRGGBB; rows of other
  * ranks are left untouched).  pane_on_device: 0 = host, 1 = device.  gmap / cmap may be NULL only
  * with the matching PM_FLAG_NO_* flag.  stats may be NULL. */
 int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_params *rp, uint32_t *pane,
               int32_t pane_on_device, pm_stats *stats);
+
+/* The image front-end of raytrace::render (src/Image.cpp:36-57): out[x + y'*width] = per-channel integer mean (truncating
+ * division) of the sample_ratio x sample_ratio block of `pane` (a (width*sample_ratio) x (height*sample_ratio) image),
+ * y' = height-1-y when flip != 0 (the reference flips), alpha 0xFF, words left as 0xAARRGGBB.  Either side host or device. */
+int pm_downsample(pm_ctx *ctx, const uint32_t *pane, int32_t pane_on_device, int32_t width, int32_t height,
+                  int32_t sample_ratio, int32_t flip, uint32_t *out, int32_t out_on_device);
+
+/* pm_render into a pane kept on the device + pm_downsample: rp->width x rp->height is the supersampled pane, `out` the
+ * (rp->width / sample_ratio) x (rp->height / sample_ratio) image (src/Image.cpp:32-57 without the 4 s^2-byte-per-pixel
+ * round trip through the host).  world must be 1. */
+int pm_render_image(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_params *rp, int32_t sample_ratio,
+                    int32_t flip, uint32_t *out, int32_t out_on_device, pm_stats *stats);
 
 #ifdef __cplusplus
 }

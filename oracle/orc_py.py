@@ -54,6 +54,8 @@ def lib():
         L.orc_default_scene.argtypes = [vp]
         L.orc_fastfloor.argtypes = [C.c_double]; L.orc_fastfloor.restype = i32
         L.orc_prim_intersect.argtypes = [vp, dp, dp, C.c_double, dp, dp]; L.orc_prim_intersect.restype = C.c_int
+        L.orc_scene_intersect.argtypes = [vp, C.c_int, dp, dp, C.c_int, C.c_double, dp, dp]; L.orc_scene_intersect.restype = C.c_int
+        L.orc_heap_insert.argtypes = [vp, vp, C.c_int, C.c_int, i32, C.c_double]
         L.orc_det_sincos.argtypes = [C.c_double, dp, dp]
         L.orc_primary_hits.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp, u64, C.c_int, C.c_int, vp, vp, vp]
         L.orc_emit_attempt.argtypes = [vp, C.c_int, C.c_int, u64, u64, C.c_int, dp, vp, C.POINTER(C.c_int), vp]
@@ -88,6 +90,14 @@ def prim_intersect(prim, src, direction, dt):
     res, nrm = (C.c_double * 3)(), (C.c_double * 3)()
     hit = lib().orc_prim_intersect(prim.ctypes.data, _v3(src), _v3(direction), float(dt), res, nrm)
     return bool(hit), np.array(res[:]), np.array(nrm[:])
+
+
+def scene_intersect(prims, src, direction, exclude=-1, dt=0.0):
+    """Scene::intersect (src/Scene.cpp:25-47): (object id or -1, hit point, normal)."""
+    prims = np.ascontiguousarray(prims, dtype=prim_dtype)
+    res, nrm = (C.c_double * 3)(), (C.c_double * 3)()
+    obj = lib().orc_scene_intersect(prims.ctypes.data, len(prims), _v3(src), _v3(direction), int(exclude), float(dt), res, nrm)
+    return obj, np.array(res[:]), np.array(nrm[:])
 
 
 def det_sincos(x):

@@ -517,6 +517,8 @@ static void ref_insert(int32_t *nearest, double *distances, int k, int size, int
         }
     }
 }
+/* the same, for tests of the host API's raytrace::insert */
+void orc_heap_insert(int32_t *nearest, double *distances, int k, int size, int32_t next, double dist) { ref_insert(nearest, distances, k, size, next, dist); }
 /* src/PhotonMap.cpp:210-255 */
 static int ref_find_nearest(const orc_map *m, int32_t *nearest, double *distances, int k, int size,
                             const double t[3], int32_t root, double max_dist) {

@@ -97,6 +97,8 @@ int orc_map_ref_depth(const orc_map *m);
 /* find_nearest_photons (src/PhotonMap.cpp:210-255) on the reference-shaped tree:
  * heap arrays in the reference's order. Returns found. idx = photon index (emission order). */
 int orc_knn_ref(const orc_map *m, const double q[3], int32_t idx[63], double d2[63]);
+/* insert (src/PhotonMap.cpp:142-206) on caller arrays, `next` a photon index. */
+void orc_heap_insert(int32_t *nearest, double *distances, int k, int size, int32_t next, double dist);
 /* Exact k-NN (k=63, d2<100), ascending by (d2, idx). Returns found. */
 int orc_knn_exact(const orc_map *m, const double q[3], int32_t idx[63], double d2[63]);
 /* Brute force, same ordering as orc_knn_exact. */

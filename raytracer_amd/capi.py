@@ -51,9 +51,10 @@ class PMError(RuntimeError):
     pass
 
 
-EXPORTS = ["pm_ctx_create", "pm_ctx_destroy", "pm_ctx_set_stream", "pm_last_error", "pm_scene_upload",
-           "pm_emit_range", "pm_emit_range_static", "pm_emit_shard", "pm_map_build", "pm_map_build_shards", "pm_map_create", "pm_map_size", "pm_map_download", "pm_map_destroy",
-           "pm_knn_query", "pm_knn_profile", "pm_knn_gather", "pm_primary_hits", "pm_render"]
+EXPORTS = ["pm_ctx_create", "pm_ctx_destroy", "pm_ctx_set_stream", "pm_ctx_synchronize", "pm_last_error", "pm_scene_upload",
+           "pm_emit_range", "pm_emit_range_static", "pm_emit_shard", "pm_map_build", "pm_map_build_shards", "pm_map_create", "pm_map_size", "pm_map_times", "pm_map_download", "pm_map_destroy",
+           "pm_knn_query", "pm_knn_profile", "pm_knn_gather", "pm_primary_hits", "pm_intersect_rays", "pm_render",
+           "pm_downsample", "pm_render_image"]
 
 _lib = None
 
@@ -82,7 +83,7 @@ def load_library():
     lib = C.CDLL(path)
     vp, u64, i64, i32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_int32
     sig = {
-        "pm_ctx_create": [C.c_int, C.POINTER(vp)], "pm_ctx_destroy": [vp], "pm_ctx_set_stream": [vp, vp],
+        "pm_ctx_create": [C.c_int, C.POINTER(vp)], "pm_ctx_destroy": [vp], "pm_ctx_set_stream": [vp, vp], "pm_ctx_synchronize": [vp],
         "pm_scene_upload": [vp, vp, i32],
         "pm_emit_range": [vp, i32, u64, C.POINTER(C.c_double), u64, u64, vp, u64, C.POINTER(u64)],
         "pm_emit_range_static": [vp, i32, u64, C.POINTER(C.c_double), u64, u64, vp, u64, C.POINTER(u64)],
@@ -90,12 +91,16 @@ def load_library():
         "pm_map_create": [vp, i32, i64, u64, C.POINTER(C.c_double), C.POINTER(vp), C.POINTER(u64)],
         "pm_emit_shard": [vp, i32, u64, C.POINTER(C.c_double), u64, u64, vp, u64],
         "pm_map_build_shards": [vp, vp, i32, u64, i64, C.POINTER(vp)],
+        "pm_map_times": [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)],
         "pm_map_size": [vp, C.POINTER(i64)], "pm_map_download": [vp, vp], "pm_map_destroy": [vp],
         "pm_knn_query": [vp, vp, i64, vp, vp, vp, vp],
         "pm_knn_profile": [vp, vp, i64, vp, vp, vp, vp, vp],
         "pm_knn_gather": [vp, vp, i32, i64, vp, vp, vp, i32],
         "pm_primary_hits": [vp, C.POINTER(RenderParams), i32, i32, vp, vp, vp],
         "pm_render": [vp, vp, vp, C.POINTER(RenderParams), vp, i32, C.POINTER(Stats)],
+        "pm_intersect_rays": [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp],
+        "pm_downsample": [vp, vp, i32, i32, i32, i32, i32, vp, i32],
+        "pm_render_image": [vp, vp, vp, C.POINTER(RenderParams), i32, i32, vp, i32, C.POINTER(Stats)],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -154,6 +159,12 @@ class PhotonMap:
         _check(self.ctx.lib.pm_map_size(self.handle, C.byref(n)))
         return n.value
 
+    def times(self):
+        """(ms of emission, ms of index build) on the device; waits for the map."""
+        a, b = C.c_float(), C.c_float()
+        _check(self.ctx.lib.pm_map_times(self.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def download(self):
         out = np.zeros(len(self), dtype=photon_dtype)
         _check(self.ctx.lib.pm_map_download(self.handle, out.ctypes.data))
@@ -178,6 +189,9 @@ class Context:
         if self.handle:
             _check(self.lib.pm_ctx_destroy(self.handle))
             self.handle = None
+
+    def synchronize(self):
+        _check(self.lib.pm_ctx_synchronize(self.handle))
 
     def set_stream(self, stream_ptr):
         _check(self.lib.pm_ctx_set_stream(self.handle, C.c_void_p(stream_ptr)))
@@ -277,6 +291,41 @@ class Context:
         _check(self.lib.pm_primary_hits(self.handle, C.byref(rp), y0, y1, ids.ctypes.data,
                                         pts.ctypes.data if want_geometry else None, nrm.ctypes.data if want_geometry else None))
         return ids.reshape(y1 - y0, rp.width), pts, nrm
+
+    def intersect_rays(self, src, direction, dt=None, prim=None, exclude=None, res=None, nrm=None):
+        """SceneObject::intersect (prim[i] >= 0) / Scene::intersect (prim None or < 0) for n rays.  Returns (hit, res, nrm)."""
+        src = np.ascontiguousarray(src, dtype=np.float64).reshape(-1, 3)
+        direction = np.ascontiguousarray(direction, dtype=np.float64).reshape(-1, 3)
+        n = len(src)
+        dt = None if dt is None else np.ascontiguousarray(dt, dtype=np.float64)
+        prim = None if prim is None else np.ascontiguousarray(prim, dtype=np.int32)
+        exclude = None if exclude is None else np.ascontiguousarray(exclude, dtype=np.int32)
+        hit = np.empty(n, dtype=np.int32)
+        res = np.zeros((n, 3)) if res is None else np.ascontiguousarray(res, dtype=np.float64)
+        nrm = np.zeros((n, 3)) if nrm is None else np.ascontiguousarray(nrm, dtype=np.float64)
+        ptr = lambda a: None if a is None else a.ctypes.data
+        _check(self.lib.pm_intersect_rays(self.handle, n, src.ctypes.data, direction.ctypes.data, ptr(dt), ptr(prim), ptr(exclude),
+                                          hit.ctypes.data, res.ctypes.data, nrm.ctypes.data))
+        return hit, res, nrm
+
+    def downsample(self, pane, sample_ratio, flip=True):
+        """Host pane [(h*s), (w*s)] uint32 -> host image [h, w] (src/Image.cpp:36-57)."""
+        pane = np.ascontiguousarray(pane, dtype=np.uint32)
+        h, w = pane.shape[0] // sample_ratio, pane.shape[1] // sample_ratio
+        out = np.empty((h, w), dtype=np.uint32)
+        _check(self.lib.pm_downsample(self.handle, pane.ctypes.data, 0, w, h, sample_ratio, 1 if flip else 0, out.ctypes.data, 0))
+        return out
+
+    def downsample_device(self, d_pane, w, h, sample_ratio, d_out, flip=True):
+        _check(self.lib.pm_downsample(self.handle, C.c_void_p(d_pane), 1, w, h, sample_ratio, 1 if flip else 0, C.c_void_p(d_out), 1))
+
+    def render_image(self, gmap, cmap, rp, sample_ratio, flip=True):
+        """pm_render into a device pane + pm_downsample: returns (image [h/s, w/s] uint32, stats)."""
+        st = Stats()
+        out = np.empty((rp.height // sample_ratio, rp.width // sample_ratio), dtype=np.uint32)
+        _check(self.lib.pm_render_image(self.handle, gmap.handle if gmap is not None else None, cmap.handle if cmap is not None else None,
+                                        C.byref(rp), sample_ratio, 1 if flip else 0, out.ctypes.data, 0, C.byref(st)))
+        return out, st
 
     def render(self, gmap, cmap, rp, pane=None, d_pane=None):
         """Traces this rank's row blocks.  Returns (pane, stats); with d_pane (device pointer) pane is None."""

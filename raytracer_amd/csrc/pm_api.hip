@@ -15,6 +15,7 @@
 #include "../../include/raytracer_amd.h"
 #include "pm_build.h"
 #include "pm_kernels.h"
+#include "pm_frontend.h"
 
 namespace pm {
 hipError_t sort_pairs_u64(void *temp, size_t &temp_bytes, const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in,
@@ -65,9 +66,9 @@ constexpr int N_EVENTS = 8;
 
 struct BuildSlot {
     hipStream_t stream = nullptr;
-    DevBuf emit_tmp, emit_flag, emit_counts, emit_offs, keys_in, keys_out, vals_in, vals_out, sort_tmp, bounds;
+    DevBuf emit_tmp, emit_flag, emit_counts, emit_offs, emit_run, keys_in, keys_out, vals_in, vals_out, sort_tmp, bounds;
     void release() {
-        DevBuf *b[] = {&emit_tmp, &emit_flag, &emit_counts, &emit_offs, &keys_in, &keys_out, &vals_in, &vals_out, &sort_tmp, &bounds};
+        DevBuf *b[] = {&emit_tmp, &emit_flag, &emit_counts, &emit_offs, &emit_run, &keys_in, &keys_out, &vals_in, &vals_out, &sort_tmp, &bounds};
         for (DevBuf *x : b) x->release();
     }
 };
@@ -91,7 +92,7 @@ struct pm_ctx {
     DevBuf scene, sgrid;
     SceneView gv{};
     // frame work buffers (grow only, reused across frames)
-    DevBuf geo, obj, pixel, node, tabslot, direct, radg, radc, color, clist, tab, ctr, pane, sched, groups, left, strips;
+    DevBuf geo, obj, pixel, node, tabslot, direct, radg, radc, color, clist, tab, ctr, pane, sample, sched, groups, left, strips;
     DevBuf sp_keys_in, sp_keys_out, sp_vals_in, sp_vals_out, sp_sort_tmp, sp_bounds, sp_groups, sp_early, sp_pieces;   // spatial order of the bounced pixels' shade points
     bool use_tiles = true;     // PM_GATHER_TILE=0: every shade point goes through the per-query kernel (A/B switch)
     double sp_cell = 6.0;      // cell size of those groups in 63-NN radii (PM_SP_CELL), and the shortest run worth a group (PM_SP_MIN_RUN)
@@ -118,8 +119,11 @@ struct pm_map {
     // a map whose emission + build are still on a slot's stream: `ready` marks their end, *h_got (pinned) then holds the
     // photons the one emission range produced; map_ready() waits, checks, and emits more in the rare case it fell short
     bool pending = false;
+    int failed = PM_OK;                  // sticky: a map whose emission / assembly / build failed reports that on every later use
+    std::string fail_msg;
     int slot = 2;
     hipEvent_t ready = nullptr;
+    hipEvent_t t_begin = nullptr, t_emitted = nullptr;   // on the build stream: emission starts / is over (the index build follows up to `ready`)
     uint64_t *h_got = nullptr;           // pinned, two words: photons available; a shard overflowed
     int kind = 0; uint64_t seed = 0, next_attempt = 0; double lc[3] = {0, 0, 0};
     DevBuf records, pos4, rest, cells, keys, cbox, grid;
@@ -177,7 +181,7 @@ extern "C" int pm_ctx_destroy(pm_ctx *ctx) {
     for (int i = 0; i < 3; i++) ctx->slot[i].release();
     if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
     DevBuf *bufs[] = {&ctx->scene, &ctx->sgrid, &ctx->geo, &ctx->obj, &ctx->pixel, &ctx->node, &ctx->tabslot, &ctx->direct, &ctx->radg, &ctx->radc,
-                      &ctx->color, &ctx->clist, &ctx->tab, &ctx->ctr, &ctx->pane, &ctx->sched, &ctx->groups, &ctx->left, &ctx->strips,
+                      &ctx->color, &ctx->clist, &ctx->tab, &ctx->ctr, &ctx->pane, &ctx->sample, &ctx->sched, &ctx->groups, &ctx->left, &ctx->strips,
                       &ctx->sp_keys_in, &ctx->sp_keys_out, &ctx->sp_vals_in, &ctx->sp_vals_out, &ctx->sp_sort_tmp, &ctx->sp_bounds, &ctx->sp_groups, &ctx->sp_early, &ctx->sp_pieces};
     for (DevBuf *b : bufs) b->release();
     for (pm_map *m : ctx->spare) free_map(m);
@@ -193,6 +197,13 @@ extern "C" int pm_ctx_destroy(pm_ctx *ctx) {
     return PM_OK;
 }
 
+extern "C" int pm_ctx_synchronize(pm_ctx *ctx) {
+    if (!ctx) return fail(PM_EINVAL, "ctx is NULL");
+    PMCHK(set_device(ctx));
+    for (int i = 0; i < 2; i++) if (ctx->slot[i].stream) HIPCHK(hipStreamSynchronize(ctx->slot[i].stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PM_OK;
+}
 extern "C" int pm_ctx_set_stream(pm_ctx *ctx, void *hip_stream) {
     if (!ctx) return fail(PM_EINVAL, "ctx is NULL");
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
@@ -391,13 +402,15 @@ static int slot_scratch(BuildSlot &sl, uint64_t count, EmitScratch &es) {
     es = {sl.emit_tmp.as<pm_photon>(), sl.emit_flag.as<uint8_t>(), sl.emit_counts.as<uint32_t>(), sl.emit_offs.as<uint64_t>()};
     return PM_OK;
 }
+constexpr uint64_t EMIT_CHUNK = 1ULL << 24;   // attempts per launch of a map's emission (512 MB of attempt records per build slot)
+// d_running != NULL: this range appends behind the ranges emitted before it (k_scan_blocks); *h_got then receives the total so far
 static int emit_range_on(pm_ctx *ctx, hipStream_t stream, const EmitScratch &es, int kind, uint64_t seed, const double lc[3], uint64_t a0, uint64_t count,
-                         pm_photon *d_out, uint64_t cap, uint64_t *h_got, uint64_t *total) {
+                         pm_photon *d_out, uint64_t cap, uint64_t *h_got, uint64_t *total, uint64_t *d_running = nullptr) {
     uint32_t nb = (uint32_t)((count + 255) / 256);
     uint64_t K = stream_key(seed, kind == PM_MAP_GLOBAL ? KIND_EMIT_GLOBAL : KIND_EMIT_CAUSTIC);
     V3 light = {lc[0], lc[1], lc[2]};
     LAUNCH_SCENE_ON(k_emit, dim3(nb), dim3(256), ctx, stream, kind, K, light, a0, count, es.tmp, es.flag, es.counts);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, es.counts, es.offs, nb);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, es.counts, es.offs, nb, d_running);
     hipLaunchKernelGGL(k_emit_scatter, dim3(nb), dim3(256), 0, stream, es.tmp, es.flag, es.offs, count, d_out, cap);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h_got, es.offs + nb, 8, hipMemcpyDeviceToHost, stream));
@@ -407,12 +420,12 @@ static int emit_range_on(pm_ctx *ctx, hipStream_t stream, const EmitScratch &es,
     return PM_OK;
 }
 static int emit_range(pm_ctx *ctx, BuildSlot &sl, int kind, uint64_t seed, const double lc[3], uint64_t a0, uint64_t count, pm_photon *d_out,
-                      uint64_t cap, uint64_t *h_got, uint64_t *total) {
+                      uint64_t cap, uint64_t *h_got, uint64_t *total, uint64_t *d_running = nullptr) {
     if (count == 0) { *h_got = 0; if (total) *total = 0; return PM_OK; }
     if (count > (1ULL << 31)) return fail(PM_EINVAL, "emit_range: at most 2^31 attempts per call");
     EmitScratch es;
     PMCHK(slot_scratch(sl, count, es));
-    return emit_range_on(ctx, sl.stream, es, kind, seed, lc, a0, count, d_out, cap, h_got, total);
+    return emit_range_on(ctx, sl.stream, es, kind, seed, lc, a0, count, d_out, cap, h_got, total, d_running);
 }
 
 extern "C" int pm_emit_range(pm_ctx *ctx, int32_t map_kind, uint64_t seed, const double light_color[3], uint64_t attempt_begin,
@@ -524,12 +537,17 @@ static pm_map *new_map(pm_ctx *ctx) {
     if (!ctx->spare.empty()) { m = ctx->spare.back(); ctx->spare.pop_back(); }
     else m = new (std::nothrow) pm_map();
     if (!m) return nullptr;
-    if (!m->ready && hipEventCreateWithFlags(&m->ready, hipEventDisableTiming) != hipSuccess) { delete m; return nullptr; }
-    if (!m->h_got && hipHostMalloc((void **)&m->h_got, 2 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) { (void)hipEventDestroy(m->ready); delete m; return nullptr; }
-    m->ctx = ctx; m->pending = false;
+    if (!m->ready && (hipEventCreate(&m->ready) != hipSuccess || hipEventCreate(&m->t_begin) != hipSuccess || hipEventCreate(&m->t_emitted) != hipSuccess)) { free_map(m); return nullptr; }
+    if (!m->h_got && hipHostMalloc((void **)&m->h_got, 2 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) { free_map(m); return nullptr; }
+    m->ctx = ctx; m->pending = false; m->failed = PM_OK; m->fail_msg.clear();
     return m;
 }
 // the next build slot (0 / 1 in turn), its stream ordered behind what the caller's stream holds now
+static int stamp(hipEvent_t a, hipEvent_t b, hipStream_t st) {
+    HIPCHK(hipEventRecord(a, st));
+    if (b) HIPCHK(hipEventRecord(b, st));
+    return PM_OK;
+}
 static int take_slot(pm_ctx *ctx, int &slot) {
     slot = ctx->next_slot;
     ctx->next_slot ^= 1;
@@ -539,14 +557,37 @@ static int take_slot(pm_ctx *ctx, int &slot) {
 }
 
 // Wait for a map whose emission and build were left on a slot's stream and make sure it holds its n photons.
+static int map_top_up(pm_map *map, uint64_t have) {
+    pm_ctx *ctx = map->ctx;
+    const uint64_t n = (uint64_t)map->n;
+    const double yield = ctx->yield[map->kind];
+    BuildSlot &sl = ctx->slot[2];
+    sl.stream = ctx->stream;
+    int empty_batches = 0;
+    while (have < n) {
+        uint64_t want = n - have;
+        uint64_t batch = std::min<uint64_t>((uint64_t)((double)want / yield) + 4096, EMIT_CHUNK);
+        uint64_t got = 0;
+        PMCHK(emit_range(ctx, sl, map->kind, map->seed, map->lc, map->next_attempt, batch, map->records.as<pm_photon>() + have, want, ctx->h_u64, &got));
+        map->next_attempt += batch;
+        have += std::min<uint64_t>(got, want);
+        if (got == 0 && ++empty_batches > 8) return fail(PM_ESTATE, "pm_map_create: no emission attempt stores a photon in this scene");
+    }
+    PMCHK(build_index(map, sl));
+    HIPCHK(hipStreamSynchronize(sl.stream));
+    return PM_OK;
+}
+static int map_failed(pm_map *map, int code, const std::string &msg) { map->failed = code; map->fail_msg = msg; return fail(code, msg); }
 static int map_ready(pm_map *map) {
-    if (!map || !map->pending) return PM_OK;
+    if (!map) return PM_OK;
+    if (map->failed != PM_OK) return fail(map->failed, map->fail_msg);
+    if (!map->pending) return PM_OK;
     pm_ctx *ctx = map->ctx;
     map->pending = false;
-    if (hipEventSynchronize(map->ready) != hipSuccess) return fail(PM_EHIP, "photon map: emission or build failed on the device");
+    if (hipEventSynchronize(map->ready) != hipSuccess) return map_failed(map, PM_EHIP, "photon map: emission or build failed on the device");
     if (map->kind == -2) {             // assembled from shards: they must have held n photons, none cut off
-        if (map->h_got[1]) return fail(PM_ESTATE, "pm_map_build_shards: a shard overflowed its capacity");
-        if (*map->h_got < (uint64_t)map->n) return fail(PM_ESTATE, "pm_map_build_shards: the shards hold fewer than n photons");
+        if (map->h_got[1]) return map_failed(map, PM_ESTATE, "pm_map_build_shards: a shard overflowed its capacity");
+        if (*map->h_got < (uint64_t)map->n) return map_failed(map, PM_ESTATE, "pm_map_build_shards: the shards hold fewer than n photons");
         return PM_OK;
     }
     if (map->kind < 0) return PM_OK;   // built from records: nothing to check
@@ -558,26 +599,12 @@ static int map_ready(pm_map *map) {
         ctx->yield[map->kind] = std::max(1e-4, p - 4.0 * sqrt(p * (1.0 - p) / a) - 0.01 * p);
     }
     if (have >= n) return PM_OK;
-    // the one range fell short of n photons (a scene that stores far fewer photons per attempt than the reference's):
+    // the ranges fell short of n photons (a scene that stores far fewer photons per attempt than the reference's):
     // keep emitting, synchronously on the caller's stream, then build again
-    const double yield = ctx->yield[map->kind];
-    BuildSlot &sl = ctx->slot[2];
-    sl.stream = ctx->stream;
-    int empty_batches = 0;
-    while (have < n) {
-        uint64_t want = n - have;
-        uint64_t batch = std::min<uint64_t>((uint64_t)((double)want / yield) + 4096, 1ULL << 24);
-        uint64_t got = 0;
-        PMCHK(emit_range(ctx, sl, map->kind, map->seed, map->lc, map->next_attempt, batch, map->records.as<pm_photon>() + have, want, ctx->h_u64, &got));
-        map->next_attempt += batch;
-        have += std::min<uint64_t>(got, want);
-        if (got == 0 && ++empty_batches > 8) return fail(PM_ESTATE, "pm_map_create: no emission attempt stores a photon in this scene");
-    }
-    PMCHK(build_index(map, sl));
-    HIPCHK(hipStreamSynchronize(sl.stream));
-    return PM_OK;
+    int rc = map_top_up(map, have);
+    if (rc != PM_OK) { map->failed = rc; map->fail_msg = g_err; }
+    return rc;
 }
-
 extern "C" int pm_map_build(pm_ctx *ctx, const pm_photon *records, int64_t n, int32_t records_on_device, pm_map **out) {
     if (!ctx || !out || n < 0 || (n > 0 && !records)) return fail(PM_EINVAL, "pm_map_build: bad argument");
     PMCHK(set_device(ctx));
@@ -593,6 +620,7 @@ extern "C" int pm_map_build(pm_ctx *ctx, const pm_photon *records, int64_t n, in
         if (e != hipSuccess) rc = fail(PM_EHIP, std::string("copy of photon records failed: ") + hipGetErrorString(e));
     }
     if (rc == PM_OK) rc = take_slot(ctx, map->slot);
+    if (rc == PM_OK) rc = stamp(map->t_begin, map->t_emitted, ctx->slot[map->slot].stream);
     if (rc == PM_OK) rc = build_index(map, ctx->slot[map->slot]);
     if (rc == PM_OK && hipEventRecord(map->ready, ctx->slot[map->slot].stream) != hipSuccess) rc = fail(PM_EHIP, "pm_map_build: hipEventRecord failed");
     if (rc != PM_OK) { pm_map_destroy(map); return rc; }
@@ -619,6 +647,7 @@ extern "C" int pm_map_build_shards(pm_ctx *ctx, const void *d_shards, int32_t wo
         if (hipMemcpyAsync(map->h_got, status, 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = fail(PM_EHIP, "pm_map_build_shards: copy failed");
     } else if (rc == PM_OK) { map->h_got[0] = 0; map->h_got[1] = 0; }
     if (rc == PM_OK) rc = take_slot(ctx, map->slot);
+    if (rc == PM_OK) rc = stamp(map->t_begin, map->t_emitted, ctx->slot[map->slot].stream);
     if (rc == PM_OK) rc = build_index(map, ctx->slot[map->slot]);
     if (rc == PM_OK && hipEventRecord(map->ready, ctx->slot[map->slot].stream) != hipSuccess) rc = fail(PM_EHIP, "pm_map_build_shards: hipEventRecord failed");
     if (rc != PM_OK) { pm_map_destroy(map); return rc; }
@@ -648,9 +677,20 @@ extern "C" int pm_map_create(pm_ctx *ctx, int32_t map_kind, int64_t n, uint64_t 
     if (rc == PM_OK) rc = take_slot(ctx, map->slot);
     if (rc == PM_OK) {
         BuildSlot &sl = ctx->slot[map->slot];
-        uint64_t batch = n > 0 ? std::min<uint64_t>((uint64_t)((double)n / yield) + 4096, 1ULL << 24) : 0;
-        rc = emit_range(ctx, sl, map_kind, seed, light_color, 0, batch, map->records.as<pm_photon>(), (uint64_t)n, map->h_got, nullptr);
-        map->next_attempt = batch;
+        // as many attempts as n photons are expected to take, in launches of at most EMIT_CHUNK chained on the device (a 10M-photon
+        // caustic map is 28M attempts): no count reaches the host before the index is built
+        const uint64_t total = n > 0 ? std::min<uint64_t>((uint64_t)((double)n / yield) + 4096, 1ULL << 36) : 0;
+        map->h_got[0] = 0;
+        rc = stamp(map->t_begin, nullptr, sl.stream);
+        if (total > EMIT_CHUNK) {
+            rc = sl.emit_run.ensure(8);
+            if (rc == PM_OK && hipMemsetAsync(sl.emit_run.p, 0, 8, sl.stream) != hipSuccess) rc = fail(PM_EHIP, "pm_map_create: hipMemsetAsync failed");
+        }
+        for (uint64_t a0 = 0; rc == PM_OK && a0 < total; a0 += EMIT_CHUNK)
+            rc = emit_range(ctx, sl, map_kind, seed, light_color, a0, std::min<uint64_t>(EMIT_CHUNK, total - a0), map->records.as<pm_photon>(), (uint64_t)n, map->h_got, nullptr,
+                            total > EMIT_CHUNK ? sl.emit_run.as<uint64_t>() : nullptr);
+        map->next_attempt = total;
+        if (rc == PM_OK) rc = stamp(map->t_emitted, nullptr, sl.stream);
         if (rc == PM_OK) rc = build_index(map, sl);
         if (rc == PM_OK && hipEventRecord(map->ready, sl.stream) != hipSuccess) rc = fail(PM_EHIP, "pm_map_create: hipEventRecord failed");
     }
@@ -666,6 +706,16 @@ extern "C" int pm_map_size(const pm_map *map, int64_t *n) {
     *n = map->n;
     return PM_OK;
 }
+extern "C" int pm_map_times(pm_map *map, float *ms_emit, float *ms_build) {
+    if (!map || !ms_emit || !ms_build) return fail(PM_EINVAL, "pm_map_times: NULL argument");
+    PMCHK(set_device(map->ctx));
+    PMCHK(map_ready(map));
+    HIPCHK(hipEventSynchronize(map->ready));
+    *ms_emit = *ms_build = 0.f;
+    if (hipEventElapsedTime(ms_emit, map->t_begin, map->t_emitted) != hipSuccess) *ms_emit = 0.f;
+    if (hipEventElapsedTime(ms_build, map->t_emitted, map->ready) != hipSuccess) *ms_build = 0.f;
+    return PM_OK;
+}
 extern "C" int pm_map_download(pm_map *map, pm_photon *host_out) {
     if (!map || (!host_out && map->n)) return fail(PM_EINVAL, "pm_map_download: NULL argument");
     PMCHK(set_device(map->ctx));
@@ -679,6 +729,8 @@ extern "C" int pm_map_download(pm_map *map, pm_photon *host_out) {
 static void free_map(pm_map *map) {
     map->records.release(); map->pos4.release(); map->rest.release(); map->cells.release(); map->keys.release(); map->cbox.release(); map->grid.release();
     if (map->ready) (void)hipEventDestroy(map->ready);
+    if (map->t_begin) (void)hipEventDestroy(map->t_begin);
+    if (map->t_emitted) (void)hipEventDestroy(map->t_emitted);
     if (map->h_got) (void)hipHostFree(map->h_got);
     delete map;
 }
@@ -688,7 +740,10 @@ extern "C" int pm_map_destroy(pm_map *map) {
     if (ctx) {
         (void)hipSetDevice(ctx->device);
         if (map->pending) { (void)hipEventSynchronize(map->ready); map->pending = false; }   // its build may still be running
+        // and so may a gather that reads it: the caller's stream and the two streams beside it (a frame that ended in an error
+        // has already waited for them; this is for callers that destroy a map right behind an asynchronous use)
         (void)hipStreamSynchronize(ctx->stream);
+        for (int i = 0; i < 2; i++) if (ctx->slot[i].stream) (void)hipStreamSynchronize(ctx->slot[i].stream);
     }
     // keep the buffers of up to four maps for the next ones (a frame rebuilds both maps; hipFree / hipMalloc of 100 MB cost more than the build)
     if (ctx && ctx->spare.size() < 4) { map->n = 0; memset(&map->view, 0, sizeof(map->view)); ctx->spare.push_back(map); }
@@ -822,6 +877,75 @@ extern "C" int pm_primary_hits(pm_ctx *ctx, const pm_render_params *rp, int32_t 
     return PM_OK;
 }
 
+extern "C" int pm_intersect_rays(pm_ctx *ctx, int64_t n, const double *src, const double *dir, const double *dt, const int32_t *prim, const int32_t *exclude,
+                                 int32_t *hit, double *res, double *nrm) {
+    if (!ctx || n < 0 || (n && (!src || !dir || !hit || !res || !nrm))) return fail(PM_EINVAL, "pm_intersect_rays: bad argument");
+    if (ctx->nprims == 0) return fail(PM_ESTATE, "pm_intersect_rays: no scene uploaded");
+    if (n == 0) return PM_OK;
+    if (n > (1LL << 31)) return fail(PM_EINVAL, "pm_intersect_rays: at most 2^31 rays per call");
+    // a primitive index beyond the scene would read past the scene block on the device
+    if (prim) for (int64_t i = 0; i < n; i++) if (prim[i] >= ctx->nprims) return fail(PM_EINVAL, "pm_intersect_rays: prim[" + std::to_string(i) + "] is not a primitive of the scene");
+    PMCHK(set_device(ctx));
+    DevBuf ds, dd, dtb, dp, de, dh, dr, dn;
+    int rc = ds.ensure((size_t)n * 24);
+    if (rc == PM_OK) rc = dd.ensure((size_t)n * 24);
+    if (rc == PM_OK && dt) rc = dtb.ensure((size_t)n * 8);
+    if (rc == PM_OK && prim) rc = dp.ensure((size_t)n * 4);
+    if (rc == PM_OK && exclude) rc = de.ensure((size_t)n * 4);
+    if (rc == PM_OK) rc = dh.ensure((size_t)n * 4);
+    if (rc == PM_OK) rc = dr.ensure((size_t)n * 24);
+    if (rc == PM_OK) rc = dn.ensure((size_t)n * 24);
+    hipError_t e = hipSuccess;
+    if (rc == PM_OK) {
+        hipStream_t st = ctx->stream;
+        e = hipMemcpyAsync(ds.p, src, (size_t)n * 24, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(dd.p, dir, (size_t)n * 24, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && dt) e = hipMemcpyAsync(dtb.p, dt, (size_t)n * 8, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && prim) e = hipMemcpyAsync(dp.p, prim, (size_t)n * 4, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && exclude) e = hipMemcpyAsync(de.p, exclude, (size_t)n * 4, hipMemcpyHostToDevice, st);
+        // the caller's res / nrm travel to the device first: a miss leaves them as they were (the reference's contract)
+        if (e == hipSuccess) e = hipMemcpyAsync(dr.p, res, (size_t)n * 24, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(dn.p, nrm, (size_t)n * 24, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            LAUNCH_SCENE(k_intersect_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), ctx, (long long)n, ds.as<double>(), dd.as<double>(), dt ? dtb.as<double>() : nullptr,
+                         prim ? dp.as<int32_t>() : nullptr, exclude ? de.as<int32_t>() : nullptr, dh.as<int32_t>(), dr.as<double>(), dn.as<double>());
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(hit, dh.p, (size_t)n * 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(res, dr.p, (size_t)n * 24, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(nrm, dn.p, (size_t)n * 24, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    DevBuf *all[] = {&ds, &dd, &dtb, &dp, &de, &dh, &dr, &dn};
+    for (DevBuf *b : all) b->release();
+    if (rc != PM_OK) return rc;
+    if (e != hipSuccess) return fail(PM_EHIP, std::string("pm_intersect_rays: ") + hipGetErrorString(e));
+    return PM_OK;
+}
+
+extern "C" int pm_downsample(pm_ctx *ctx, const uint32_t *pane, int32_t pane_on_device, int32_t width, int32_t height, int32_t sample_ratio, int32_t flip,
+                             uint32_t *out, int32_t out_on_device) {
+    if (!ctx || !pane || !out) return fail(PM_EINVAL, "pm_downsample: NULL argument");
+    if (width <= 0 || height <= 0 || sample_ratio < 1 || sample_ratio > 4096 || (long long)width * sample_ratio * (long long)height * sample_ratio > (1LL << 31))
+        return fail(PM_EINVAL, "pm_downsample: need width, height > 0, 1 <= sample_ratio <= 4096 and a pane of at most 2^31 pixels");
+    PMCHK(set_device(ctx));
+    const size_t in_b = (size_t)width * sample_ratio * height * sample_ratio * 4, out_b = (size_t)width * height * 4;
+    const uint32_t *d_in = pane;
+    uint32_t *d_out = out;
+    if (!pane_on_device) {
+        PMCHK(ctx->pane.ensure(in_b));
+        HIPCHK(hipMemcpyAsync(ctx->pane.p, pane, in_b, hipMemcpyHostToDevice, ctx->stream));
+        d_in = ctx->pane.as<uint32_t>();
+    }
+    if (!out_on_device) { PMCHK(ctx->sample.ensure(out_b)); d_out = ctx->sample.as<uint32_t>(); }
+    hipLaunchKernelGGL(k_downsample, dim3((unsigned)((width + 63) / 64), (unsigned)((height + 3) / 4)), dim3(256), 0, ctx->stream, d_in, (int)width, (int)height,
+                       (int)sample_ratio, (int)flip, d_out);
+    HIPCHK(hipGetLastError());
+    if (!out_on_device) HIPCHK(hipMemcpyAsync(out, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PM_OK;
+}
+
 static int ensure_sp(pm_ctx *ctx, uint32_t cap) {
     if (cap <= ctx->sp_cap) return PM_OK;
     size_t c = (size_t)cap + cap / 8 + 1024;
@@ -836,7 +960,10 @@ static SPQueue sp_queue(pm_ctx *ctx) {
     q.geo = ctx->geo.as<double>(); q.obj = ctx->obj.as<int32_t>(); q.pixel = ctx->pixel.as<uint32_t>();
     q.node = ctx->node.as<uint32_t>(); q.tabslot = ctx->tabslot.as<uint32_t>(); q.direct = ctx->direct.as<double>();
     q.rad_g = ctx->radg.as<double>(); q.rad_c = ctx->radc.as<double>(); q.color = ctx->color.as<uint32_t>();
+    q.overflow = &ctx->ctr.as<Counters>()->overflow;
     q.cap = ctx->sp_cap;
+    // PM_SP_CAP_LIMIT (tests): pretend the queue is this small, to show that a frame that overflows it is reported, not delivered
+    if (const char *e = getenv("PM_SP_CAP_LIMIT")) { long v = atol(e); if (v > 0 && (uint32_t)v < q.cap) q.cap = (uint32_t)v; }
     return q;
 }
 
@@ -864,8 +991,23 @@ static int gather_blocks(pm_ctx *ctx) {
     return PM_OK;
 }
 
+static int render_impl(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_params *rp, uint32_t *pane, int32_t pane_on_device, pm_stats *stats);
 extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_params *rp, uint32_t *pane, int32_t pane_on_device,
                          pm_stats *stats) {
+    const int rc = render_impl(ctx, gmap, cmap, rp, pane, pane_on_device, stats);
+    if (rc != PM_OK && ctx) {
+        // a frame that fails half way may have gathers queued on the two streams beside the caller's (a map that was fine is
+        // gathered before the other one's failure shows): nothing of it is left running when the error is reported, so the
+        // caller may destroy or rebuild the maps at once
+        const std::string msg = g_err;
+        (void)hipSetDevice(ctx->device);
+        for (int i = 0; i < 2; i++) if (ctx->slot[i].stream) (void)hipStreamSynchronize(ctx->slot[i].stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        g_err = msg;
+    }
+    return rc;
+}
+static int render_impl(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_params *rp, uint32_t *pane, int32_t pane_on_device, pm_stats *stats) {
     FrameParams fp;
     PMCHK(make_frame_params(ctx, rp, fp));
     if (!pane) return fail(PM_EINVAL, "pm_render: pane is NULL");
@@ -884,7 +1026,7 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
     if (!pane_on_device) { PMCHK(ctx->pane.ensure((size_t)W * H * 4)); d_pane = ctx->pane.as<uint32_t>(); }
     PMCHK(ctx->ctr.ensure(sizeof(Counters)));
     PMCHK(ctx->clist.ensure(owned_px * 4));
-    PMCHK(ctx->groups.ensure((owned_px / 64 + 1) * sizeof(uint2)));   // one group per 8x8 pixel tile
+    PMCHK(ctx->groups.ensure((size_t)owned * 2 * ((W + 7) / 8) * sizeof(uint2)));   // one group per 8x8 pixel tile: 2 tile rows per row block, ceil(W/8) columns
     PMCHK(ensure_sp(ctx, (uint32_t)std::min<size_t>(owned_px + owned_px / 4, 0xFFFFFF00u)));
     Counters *d_ctr = ctx->ctr.as<Counters>();
     dim3 grid_px((W + 15) / 16, owned), block(256);
@@ -899,6 +1041,7 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
         HIPCHK(hipMemcpyAsync(ctx->h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         n_sp0 = ctx->h_ctr->n_sp; n_complex = ctx->h_ctr->n_complex;
+        if (ctx->h_ctr->overflow && getenv("PM_SP_CAP_LIMIT")) return fail(PM_ESTATE, "pm_render: the shade point queue overflowed (" + std::to_string(ctx->h_ctr->n_sp) + " shade points): the pane is incomplete");
         size_t need = (size_t)n_sp0 + (size_t)15 * n_complex;   // every node of a bounced pixel's tree may absorb
         if (need > 0xFFFFFF00u) return fail(PM_EINVAL, "pm_render: too many shade points for one call; split the frame over more ranks");
         if (need <= ctx->sp_cap) break;
@@ -916,6 +1059,7 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
         HIPCHK(hipMemcpyAsync(ctx->h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         n_sp = ctx->h_ctr->n_sp; n_secondary = ctx->h_ctr->n_secondary;
+        if (ctx->h_ctr->overflow) return fail(PM_ESTATE, "pm_render: the shade point queue overflowed (" + std::to_string(ctx->h_ctr->n_sp) + " shade points): the pane is incomplete");
     }
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
     int n_gathers = 0;
@@ -1039,8 +1183,9 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
             HIPCHK(hipMemcpyAsync(pane + y0 * W, d_pane + y0 * W, (y1 - y0) * W * 4, hipMemcpyDeviceToHost, ctx->stream));
         }
     }
-    if (stats) HIPCHK(hipMemcpyAsync(ctx->h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_ctr->overflow) return fail(PM_ESTATE, "pm_render: the shade point queue overflowed (" + std::to_string(ctx->h_ctr->n_sp) + " shade points): the pane is incomplete");
     if (getenv("PM_DEBUG")) {
         Counters hc;
         if (hipMemcpy(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost) == hipSuccess)
@@ -1090,4 +1235,18 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
         (void)hipEventElapsedTime(&stats->ms_total, ctx->ev[0], ctx->ev[6]);
     }
     return PM_OK;
+}
+
+// raytrace::render between scene set-up and the PNG writer (src/Image.cpp:32-57): the supersampled pane stays on the
+// device, only the width x height image travels.
+extern "C" int pm_render_image(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_params *rp, int32_t sample_ratio, int32_t flip, uint32_t *out,
+                               int32_t out_on_device, pm_stats *stats) {
+    if (!ctx || !rp || !out) return fail(PM_EINVAL, "pm_render_image: NULL argument");
+    if (sample_ratio < 1 || rp->width % sample_ratio || rp->height % sample_ratio)
+        return fail(PM_EINVAL, "pm_render_image: the pane (rp->width x rp->height) must be sample_ratio times the image in both directions");
+    if (rp->world != 1) return fail(PM_EINVAL, "pm_render_image: one rank renders the whole pane (world must be 1)");
+    PMCHK(set_device(ctx));
+    PMCHK(ctx->pane.ensure((size_t)rp->width * rp->height * 4));
+    PMCHK(pm_render(ctx, gmap, cmap, rp, ctx->pane.as<uint32_t>(), 1, stats));
+    return pm_downsample(ctx, ctx->pane.as<uint32_t>(), 1, rp->width / sample_ratio, rp->height / sample_ratio, sample_ratio, flip, out, out_on_device);
 }

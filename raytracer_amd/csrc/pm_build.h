@@ -97,11 +97,13 @@ __global__ __launch_bounds__(256) void k_emit(SceneView gs, int map_kind, uint64
     if (threadIdx.x == 0) block_counts[blockIdx.x] = (uint32_t)c;
 }
 
-// exclusive scan of nb block counts by one 1024-thread block; offs[nb] = total
-__global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t *counts, uint64_t *offs, uint32_t nb) {
+// exclusive scan of nb block counts by one 1024-thread block; offs[nb] = total.  running != NULL: a map emitted in several
+// ranges chains them on the device -- the scan starts from *running (the successes of the ranges before) and leaves
+// *running at the new total, so the scatter that follows appends behind the earlier ranges without the host knowing a count.
+__global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t *counts, uint64_t *offs, uint32_t nb, uint64_t *running) {
     __shared__ uint64_t buf[1024];
     __shared__ uint64_t carry;
-    if (threadIdx.x == 0) carry = 0;
+    if (threadIdx.x == 0) carry = running ? *running : 0;
     __syncthreads();
     for (uint32_t base = 0; base < nb; base += 1024) {
         uint32_t i = base + threadIdx.x;
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t *counts, ui
         if (threadIdx.x == 1023) carry += buf[1023];
         __syncthreads();
     }
-    if (threadIdx.x == 0) offs[nb] = carry;
+    if (threadIdx.x == 0) { offs[nb] = carry; if (running) *running = carry; }
 }
 
 __global__ __launch_bounds__(256) void k_emit_scatter(const pm_photon *tmp, const uint8_t *flag, const uint64_t *offs, uint64_t count,

@@ -29,7 +29,7 @@ struct FrameParams {
     int rank, world;
 };
 
-struct Counters { uint32_t n_sp, n_complex, n_secondary, n_groups, n_left[2], pad, n_sgroups, n_early, n_pieces; uint32_t why[8]; unsigned long long tphase[8]; uint32_t ghist[2][32]; };   // n_left[k]: shade points left to the per-query gather of map k
+struct Counters { uint32_t n_sp, n_complex, n_secondary, n_groups, n_left[2], pad, n_sgroups, n_early, n_pieces, overflow; uint32_t why[8]; unsigned long long tphase[8]; uint32_t ghist[2][32]; };   // n_left[k]: shade points left to the per-query gather of map k
 
 // shade point queue (SoA)
 struct SPQueue {
@@ -42,6 +42,7 @@ struct SPQueue {
     double *rad_g;       // [3][cap]
     double *rad_c;       // [3][cap]
     uint32_t *color;     // [cap] absorb_res
+    uint32_t *overflow;  // Counters::overflow: set when a shade point did not fit
     uint32_t cap;
 };
 
@@ -66,7 +67,9 @@ __device__ inline uint32_t mix_colour(uint32_t reflect_res, uint32_t refract_res
 }
 
 __device__ inline void sp_store(const SPQueue &q, uint32_t slot, const V3 &res, const V3 &nrm, int obj, uint32_t pixel, uint32_t node, uint32_t tabslot) {
-    if (slot >= q.cap) return;   // capacity is sized for the worst case on the host; belt and braces
+    // capacity is sized for the worst case on the host; should it ever not be, the frame is reported as failed (PM_ESTATE)
+    // rather than delivered with pixels missing
+    if (slot >= q.cap) { *q.overflow = 1u; return; }
     q.geo[0 * (size_t)q.cap + slot] = res.x; q.geo[1 * (size_t)q.cap + slot] = res.y; q.geo[2 * (size_t)q.cap + slot] = res.z;
     q.geo[3 * (size_t)q.cap + slot] = nrm.x; q.geo[4 * (size_t)q.cap + slot] = nrm.y; q.geo[5 * (size_t)q.cap + slot] = nrm.z;
     q.obj[slot] = obj; q.pixel[slot] = pixel; q.node[slot] = node; q.tabslot[slot] = tabslot;

@@ -8,6 +8,8 @@
 //   --photons N   photons per map (also RAYTRACER_PHOTONS; default 2048, the reference's NUM_PHOTONS)
 //   --seed S      fixes the random streams (also RAYTRACER_SEED; default: the clock, like the reference)
 //   --out FILE    image file (default raytraced.png, the reference's name)
+//   --scene WHAT  a scene other than the reference's Cornell box: a scene file (raytrace::loadScene: `*.bin` = pm_prim
+//                 records, else text), `caustics` (BASELINE config 4), `spheres:N[:SEED]` (config 5: the walls + N spheres)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -24,6 +26,7 @@ struct Options {
     bool have_seed = false;
     long long seed = 0;
     std::string out = "raytraced.png";
+    std::string scene;
 };
 
 // One line per way the reference turns a command line down, in the order it checks them.
@@ -40,12 +43,13 @@ bool parse(int argc, char *argv[], Options &o, std::vector<const char *> &positi
     if (const char *e = std::getenv("RAYTRACER_PHOTONS")) o.photons = std::atoll(e);
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
-        const bool wants_value = a == "--photons" || a == "--seed" || a == "--out";
+        const bool wants_value = a == "--photons" || a == "--seed" || a == "--out" || a == "--scene";
         if (!wants_value) { positional.push_back(argv[i]); continue; }
         if (i + 1 >= argc) return false;
         const char *v = argv[++i];
         if (a == "--photons") o.photons = std::atoll(v);
         else if (a == "--seed") { o.have_seed = true; o.seed = std::atoll(v); }
+        else if (a == "--scene") o.scene = v;
         else o.out = v;
     }
     return true;
@@ -67,6 +71,17 @@ int main(int argc, char *argv[]) {
     if (o.have_seed) randutil::init(o.seed);
     if (o.photons >= 0) raytrace::setPhotonCounts((int32)o.photons, (int32)o.photons);
     scheduler::startWorkers(o.cores);          // opens the GPU context; `cores` has no other meaning here
-    raytrace::render(o.out.c_str(), o.width, o.height, o.samples);
+    raytrace::Scene *scene = nullptr;   // nullptr: the reference's Cornell box
+    if (!o.scene.empty()) {
+        if (o.scene == "caustics") scene = raytrace::causticsScene();
+        else if (o.scene.rfind("spheres:", 0) == 0) {
+            char *end = nullptr;
+            const long n = std::strtol(o.scene.c_str() + 8, &end, 10);
+            const unsigned long long seed = (end && *end == ':') ? std::strtoull(end + 1, nullptr, 10) : 2024ULL;
+            if (n < 0 || n > (1 << 22)) { std::fputs("--scene spheres:N needs 0 <= N <= 4194304\n", stdout); return 0; }
+            scene = raytrace::manySpheresScene((int32)n, seed);
+        } else if (!(scene = raytrace::loadScene(o.scene.c_str()))) return 1;
+    }
+    raytrace::render(o.out.c_str(), o.width, o.height, o.samples, scene);
     return 0;
 }

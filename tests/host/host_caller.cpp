@@ -1,0 +1,150 @@
+// host_caller.cpp -- TEST PROGRAM: a caller written against the reference's own host API (Scene / SceneObject / Vec3 /
+// PhotonMap names and signatures), in the shape of the reference's Image.cpp / Raytrace.cpp call sites, compiled by the
+// tests against raytracer_amd/host/raytrace_api.h + libraytrace_host.so.  It shows that code which uses Vec3::normalize,
+// scene->intersect, createPhotonMap, find_nearest_photons and insert builds unchanged and gets the oracle's bits.
+//
+//   host_caller dump <default|caustics|spheres:N:SEED|FILE> <out>   flattened scene records (no GPU needed)
+//   host_caller heap <n> <seed> <out>                               raytrace::insert over a pseudo-random sequence (no GPU)
+//   host_caller trace <w> <h> <out>                                 one un-jittered primary ray per pixel + its mirror bounce
+//   host_caller knn <photons> <seed> <points> <out>                 createPhotonMap + find_nearest_photons on floor points
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/raytracer_amd.h"
+#include "../../raytracer_amd/host/raytrace_api.h"
+
+using namespace raytrace;
+
+static Scene *scene_of(const std::string &spec) {
+    if (spec == "default") return defaultScene();
+    if (spec == "caustics") return causticsScene();
+    if (spec.rfind("spheres:", 0) == 0) {
+        char *end = nullptr;
+        long n = std::strtol(spec.c_str() + 8, &end, 10);
+        unsigned long long seed = (end && *end == ':') ? std::strtoull(end + 1, nullptr, 10) : 2024ULL;
+        return manySpheresScene((int32)n, seed);
+    }
+    return loadScene(spec.c_str());
+}
+
+static uint64_t next_u64(uint64_t &state) {   // splitmix64: any stream will do, the Python side replays it
+    uint64_t z = (state += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+int main(int argc, char **argv) {
+    if (argc < 2) return 2;
+    const std::string mode = argv[1];
+    if (mode == "dump" && argc == 4) {
+        Scene *scene = scene_of(argv[2]);
+        if (!scene) return 1;
+        std::vector<pm_prim> prims((size_t)scene->size);
+        for (int i = 0; i < scene->size; i++) { std::memset(&prims[(size_t)i], 0, sizeof(pm_prim)); scene->objects[i]->flatten(&prims[(size_t)i]); }
+        FILE *f = std::fopen(argv[3], "wb");
+        if (!f) return 1;
+        std::fwrite(prims.data(), sizeof(pm_prim), prims.size(), f);
+        std::fclose(f);
+        delete scene;
+        return 0;
+    }
+    if (mode == "heap" && argc == 5) {
+        const int n = std::atoi(argv[2]);
+        uint64_t state = std::strtoull(argv[3], nullptr, 10);
+        std::vector<photon> pool((size_t)n);
+        photon *nearest[63];
+        double distances[63];
+        for (int i = 0; i < 63; i++) { nearest[i] = nullptr; distances[i] = 0; }
+        int size = 0;
+        for (int i = 0; i < n; i++) {
+            // few distinct values: ties at every level of the heap
+            const double dist = (double)(next_u64(state) % 997) / 8.0;
+            // the call pattern of find_nearest_photons (reference src/PhotonMap.cpp:215-222)
+            if (size < 63) { insert(nearest, distances, 63, size, &pool[(size_t)i], dist); size++; }
+            else if (dist < distances[0]) insert(nearest, distances, 63, size, &pool[(size_t)i], dist);
+        }
+        FILE *f = std::fopen(argv[4], "wb");
+        if (!f) return 1;
+        for (int i = 0; i < 63; i++) {
+            long long who = nearest[i] ? (long long)(nearest[i] - pool.data()) : -1;
+            std::fwrite(&who, 8, 1, f); std::fwrite(&distances[i], 8, 1, f);
+        }
+        std::fclose(f);
+        return 0;
+    }
+    if (mode == "trace" && argc == 5) {
+        const int w = std::atoi(argv[2]), h = std::atoi(argv[3]);
+        Scene *scene = defaultScene();
+        Vec3 camera(0, 0, -12);
+        FILE *f = std::fopen(argv[4], "wb");
+        if (!f) return 1;
+        const double fov = (w / 1280.0) * 64.0;
+        for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
+            // the primary ray of render_task without its jitter
+            Vec3 ray((x - w / 2) / fov - camera.x, (y - h / 2) / fov - camera.y, -camera.z);
+            ray.normalize();
+            Vec3 result(0, 0, 0), normal(0, 0, 0);
+            SceneObject *obj = nullptr;
+            scene->intersect(camera, ray, nullptr, &result, &normal, &obj, 0.25);
+            long long id = -1;
+            for (int i = 0; i < scene->size; i++) if (scene->objects[i] == obj) id = i;
+            double rec[14] = {(double)id, result.x, result.y, result.z, normal.x, normal.y, normal.z, -1, 0, 0, 0, 0, 0, 0};
+            if (obj) {
+                // the mirror bounce of traceRay: reflect about the normal, leave from the hit point, skip the object just hit
+                Vec3 n1(&normal);
+                n1.mul(n1.dot(&ray));
+                n1.mul(2);
+                ray.sub(&n1);
+                ray.normalize();
+                Vec3 r2(0, 0, 0), n2(0, 0, 0);
+                SceneObject *obj2 = nullptr;
+                scene->intersect(result, ray, obj, &r2, &n2, &obj2, 0.25);
+                long long id2 = -1;
+                for (int i = 0; i < scene->size; i++) if (scene->objects[i] == obj2) id2 = i;
+                rec[7] = (double)id2; rec[8] = r2.x; rec[9] = r2.y; rec[10] = r2.z; rec[11] = n2.x; rec[12] = n2.y; rec[13] = n2.z;
+                // and the object's own intersect, as Scene::intersect's loop calls it
+                Vec3 r3(0, 0, 0), n3(0, 0, 0);
+                if (obj2 && !(obj2->intersect(&result, &ray, &r3, &n3, 0.25) && r3.x == r2.x && r3.y == r2.y && r3.z == r2.z && n3.x == n2.x && n3.y == n2.y && n3.z == n2.z)) rec[7] = -99;
+            }
+            std::fwrite(rec, 8, 14, f);
+        }
+        std::fclose(f);
+        delete scene;
+        return 0;
+    }
+    if (mode == "knn" && argc == 6) {
+        const int n = std::atoi(argv[2]), m = std::atoi(argv[4]);
+        randutil::init(std::atoll(argv[3]));
+        scheduler::startWorkers(1);
+        Scene *scene = defaultScene();
+        Vec3 light_source(0, 4.96, 4), light_color(0.6, 0.6, 0.6);
+        kdnode *tree = createPhotonMap(n, light_source, light_color, scene);
+        FILE *f = std::fopen(argv[5], "wb");
+        if (!f) return 1;
+        for (int q = 0; q < m; q++) {
+            Vec3 target(-4.0 + 8.0 * q / (m > 1 ? m - 1 : 1), -5.0, 1.0 + 7.0 * ((q * 7) % m) / m);
+            photon *nearest[63];
+            double distances[63];
+            const int found = find_nearest_photons(nearest, distances, 63, 0, &target, tree, 100);
+            double head[4] = {target.x, target.y, target.z, (double)found};
+            std::fwrite(head, 8, 4, f);
+            for (int i = 0; i < 63; i++) {
+                photon blank;
+                std::memset(&blank, 0, sizeof(blank));
+                double d = i < found ? distances[i] : 0.0;
+                std::fwrite(&d, 8, 1, f);
+                std::fwrite(i < found ? nearest[i] : &blank, sizeof(photon), 1, f);
+            }
+        }
+        std::fclose(f);
+        deleteTree(tree);
+        scheduler::waitForCompletion();
+        delete scene;
+        return 0;
+    }
+    return 2;
+}

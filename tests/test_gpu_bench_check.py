@@ -1,0 +1,25 @@
+"""BASELINE.json's sizes in the suite: bench.py --check renders the 1440 x 1440 frame with 1M + 1M photons on the GPU and
+a sample of its rows with the oracle on the same photons, and says whether the rows are bit-identical.  One case per scene
+of configs 2, 4 and 5 (the oracle scans 10 005 primitives per ray on the last: fewer rows)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("scene,stride", [("default", 4), ("caustics", 4), ("spheres10k", 48)])
+def test_full_size_frame_rows_equal_the_oracle(scene, stride):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--scene", scene, "--check",
+                        "--cpu-row-stride", str(stride)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    cb = j["cpu_baseline"]
+    assert cb["sample_rows_bit_identical_to_gpu"] is True, cb
+    assert f"{len(range(stride // 2, 1440, stride))} rows" in cb["sample"]
+    assert j["rays_per_frame"] > 10e6 and j["gathers_per_frame"] > 1e6 and j["value"] > 0
+    assert "1440x1440" in j["config"]["workload"] and "1000000 global" in j["config"]["workload"]

@@ -67,8 +67,9 @@ def test_emission_vs_reference_golden(gpu_ctx, kind):
     for f in ("x", "y", "z", "dx", "dy", "dz"):
         ulp = np.abs(got[f].view(np.int32).astype(np.int64) - g[f].view(np.int32).astype(np.int64))
         assert ulp.max() <= 2, (f, ulp.max())
-    same = sum(int(np.array_equal(got[f], g[f])) for f in ("x", "y", "z"))
-    assert (got.tobytes() == g.tobytes()) or same >= 0
+    # and the difference is rare: all but a handful of the 6 x 2048 coordinates are the reference's very bits
+    differing = sum(int((got[f] != g[f]).sum()) for f in ("x", "y", "z", "dx", "dy", "dz"))
+    assert differing <= 6 * 2048 // 100, differing
 
 
 def _query_points(orc, w, h, seed, step=5):
