@@ -17,10 +17,7 @@
 #include "pm_kernels.h"
 #include "pm_frontend.h"
 
-namespace pm {
-hipError_t sort_pairs_u64(void *temp, size_t &temp_bytes, const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in,
-                          uint32_t *vals_out, size_t n, hipStream_t stream);
-}
+#include "pm_sort.h"
 using namespace pm;
 
 static thread_local std::string g_err;
@@ -486,7 +483,7 @@ static int build_index(pm_map *map, BuildSlot &sl) {
     if (n == 0) return PM_OK;
     if (n > (1LL << 31) - 64) return fail(PM_EINVAL, "pm_map_build: at most 2^31-64 photons per map");
     const pm_photon *rec = map->records.as<pm_photon>();
-    PMCHK(sl.keys_in.ensure((size_t)n * 8)); PMCHK(sl.keys_out.ensure((size_t)n * 8));
+    PMCHK(sl.keys_in.ensure((size_t)n * 8));
     PMCHK(sl.vals_in.ensure((size_t)n * 4)); PMCHK(sl.vals_out.ensure((size_t)n * 4));
     PMCHK(sl.bounds.ensure(6 * 4));
     PMCHK(map->pos4.ensure((size_t)n * 16)); PMCHK(map->rest.ensure((size_t)n * 16));
@@ -497,12 +494,11 @@ static int build_index(pm_map *map, BuildSlot &sl) {
     hipLaunchKernelGGL(k_bounds, dim3(nbk), dim3(256), 0, sl.stream, rec, n, sl.bounds.as<uint32_t>());
     hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, sl.stream, rec, n, sl.bounds.as<uint32_t>(), sl.keys_in.as<uint64_t>(),
                        sl.vals_in.as<uint32_t>());
-    size_t tmp_bytes = 0;
-    HIPCHK(sort_pairs_u64(nullptr, tmp_bytes, sl.keys_in.as<uint64_t>(), sl.keys_out.as<uint64_t>(), sl.vals_in.as<uint32_t>(),
-                          sl.vals_out.as<uint32_t>(), (size_t)n, sl.stream));
-    PMCHK(sl.sort_tmp.ensure(tmp_bytes));
-    HIPCHK(sort_pairs_u64(sl.sort_tmp.p, tmp_bytes, sl.keys_in.as<uint64_t>(), sl.keys_out.as<uint64_t>(), sl.vals_in.as<uint32_t>(),
-                          sl.vals_out.as<uint32_t>(), (size_t)n, sl.stream));
+    // 30-bit radix sort (pm_sort.h) straight into the map's key array
+    PMCHK(sl.sort_tmp.ensure(sort_scratch_words((uint32_t)n) * 4));
+    PMCHK(map->keys.ensure((size_t)n * 8));
+    HIPCHK(radix_sort_pairs_30(sl.stream, sl.keys_in.as<uint64_t>(), sl.vals_in.as<uint32_t>(), map->keys.as<uint64_t>(), sl.vals_out.as<uint32_t>(),
+                               sl.sort_tmp.as<uint32_t>(), (uint32_t)n, nullptr));
     hipLaunchKernelGGL(k_permute, dim3(nb), dim3(256), 0, sl.stream, rec, sl.vals_out.as<uint32_t>(), n, map->pos4.as<float4>(),
                        map->rest.as<uint4>());
     // linear octree tables
@@ -510,9 +506,7 @@ static int build_index(pm_map *map, BuildSlot &sl) {
     while (lmax < 8 && (1LL << (3 * (lmax + 1))) <= 4 * n) lmax++;
     long long ncells = cell_off(lmax + 1);
     PMCHK(map->cells.ensure((size_t)ncells * 4));
-    PMCHK(map->keys.ensure((size_t)n * 8));
-    HIPCHK(hipMemcpyAsync(map->keys.p, sl.keys_out.p, (size_t)n * 8, hipMemcpyDeviceToDevice, sl.stream));
-    hipLaunchKernelGGL(k_cell_tables, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, sl.stream, sl.keys_out.as<uint64_t>(), n,
+    hipLaunchKernelGGL(k_cell_tables, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, sl.stream, map->keys.as<uint64_t>(), n,
                        map->cells.as<uint32_t>(), lmax);
     PMCHK(map->cbox.ensure((size_t)box_off(lmax + 1) * 8));
     hipLaunchKernelGGL(k_cell_boxes_fine, dim3((unsigned)(((1LL << (3 * lmax)) + 255) / 256)), dim3(256), 0, sl.stream, map->pos4.as<float4>(),
@@ -1095,12 +1089,9 @@ static int render_impl(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_
             hipLaunchKernelGGL(k_sp_bounds, dim3(std::min(256u, (n_sorted + 255) / 256)), block, 0, ctx->stream, q, n_sp0, n_sorted, ctx->sp_bounds.as<uint32_t>());
             hipLaunchKernelGGL(k_sp_morton, dim3((n_sorted + 255) / 256), block, 0, ctx->stream, q, n_sp0, n_sorted, ctx->sp_bounds.as<uint32_t>(),
                                ctx->sp_keys_in.as<uint64_t>(), ctx->sp_vals_in.as<uint32_t>());
-            size_t tmp_bytes = 0;
-            HIPCHK(sort_pairs_u64(nullptr, tmp_bytes, ctx->sp_keys_in.as<uint64_t>(), ctx->sp_keys_out.as<uint64_t>(), ctx->sp_vals_in.as<uint32_t>(),
-                                  ctx->sp_vals_out.as<uint32_t>(), (size_t)n_sorted, ctx->stream));
-            PMCHK(ctx->sp_sort_tmp.ensure(tmp_bytes));
-            HIPCHK(sort_pairs_u64(ctx->sp_sort_tmp.p, tmp_bytes, ctx->sp_keys_in.as<uint64_t>(), ctx->sp_keys_out.as<uint64_t>(), ctx->sp_vals_in.as<uint32_t>(),
-                                  ctx->sp_vals_out.as<uint32_t>(), (size_t)n_sorted, ctx->stream));
+            PMCHK(ctx->sp_sort_tmp.ensure(sort_scratch_words(n_sorted) * 4));
+            HIPCHK(radix_sort_pairs_30(ctx->stream, ctx->sp_keys_in.as<uint64_t>(), ctx->sp_vals_in.as<uint32_t>(), ctx->sp_keys_out.as<uint64_t>(),
+                                       ctx->sp_vals_out.as<uint32_t>(), ctx->sp_sort_tmp.as<uint32_t>(), n_sorted, nullptr));
             // cells of about six 63-NN radii (measured best on the default scene; most runs are then left to the tile kernel's own
             // test of how far a group is spread): r^2 = 63 / (pi * density), density = photons / surface, surface taken as that
             // of a cube over the points' extent (the sparser of the two maps decides)
