@@ -97,7 +97,8 @@ struct pm_ctx {
     double sp_est = 1.0;       // a piece is grouped when its expected candidate set is within this many times PM_TILE_EST_MAX (PM_SP_EST)
     bool group_bounced = true; // PM_GROUP_BOUNCED=0: the bounced pixels' shade points stay with the per-query kernel (A/B switch)
     int tile_blocks = 0, query_blocks = 0;   // resident blocks of the two gather kernels on this device
-    uint32_t sp_cap = 0;
+    uint32_t sp_cap = 0, c_cap = 0, b_cap = 0;   // slots of the shade point queue; node tables (bounced pixels); bounced pixels' shade points the spatial sort takes
+    bool yield_known[2] = {false, false};        // a map of this scene and kind has reported what an emission attempt yields
     Counters *h_ctr = nullptr;   // pinned
     uint64_t *h_u64 = nullptr;   // pinned scratch (2 words)
     // emission / build scratch: slots 0 and 1 have streams of their own (pm_map_create / pm_map_build leave the work there
@@ -329,6 +330,7 @@ extern "C" int pm_scene_upload(pm_ctx *ctx, const pm_prim *prims, int32_t n) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->nprims = n; ctx->stride = stride; ctx->scene_b = bytes;
     ctx->yield[0] = 0.60; ctx->yield[1] = 0.36;
+    ctx->yield_known[0] = ctx->yield_known[1] = false;
     ctx->scene_mode = bytes <= LDS_SCENE_MAX ? SCENE_LDS : SCENE_GLOBAL;
     unsigned char *d = ctx->scene.as<unsigned char>();
     ctx->gv = SceneView{};
@@ -572,7 +574,7 @@ static int map_top_up(pm_map *map, uint64_t have) {
     return PM_OK;
 }
 static int map_failed(pm_map *map, int code, const std::string &msg) { map->failed = code; map->fail_msg = msg; return fail(code, msg); }
-static int map_ready(pm_map *map) {
+static int map_ready(pm_map *map, bool *rebuilt = nullptr) {
     if (!map) return PM_OK;
     if (map->failed != PM_OK) return fail(map->failed, map->fail_msg);
     if (!map->pending) return PM_OK;
@@ -591,12 +593,14 @@ static int map_ready(pm_map *map) {
         // what this scene really yields, less four standard deviations and a hundredth: the next map's range is sized by it
         const double a = (double)map->next_attempt, p = (double)*map->h_got / a;
         ctx->yield[map->kind] = std::max(1e-4, p - 4.0 * sqrt(p * (1.0 - p) / a) - 0.01 * p);
+        ctx->yield_known[map->kind] = true;
     }
     if (have >= n) return PM_OK;
     // the ranges fell short of n photons (a scene that stores far fewer photons per attempt than the reference's):
     // keep emitting, synchronously on the caller's stream, then build again
     int rc = map_top_up(map, have);
     if (rc != PM_OK) { map->failed = rc; map->fail_msg = g_err; }
+    else if (rebuilt) *rebuilt = true;
     return rc;
 }
 extern "C" int pm_map_build(pm_ctx *ctx, const pm_photon *records, int64_t n, int32_t records_on_device, pm_map **out) {
@@ -1001,6 +1005,127 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
     }
     return rc;
 }
+// One frame, queued without a host wait: every count a later kernel needs (shade points, bounced pixels, groups, what the
+// group kernel leaves) stays on the device, launches are sized for the capacity of the queues, and the maps are waited for by
+// the streams (hipStreamWaitEvent), not by the host.  The host looks at the frame once, when it is over (render_impl).
+static int enqueue_frame(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_params *rp, const FrameParams &fp, uint32_t *d_pane, int owned, bool gathered[2]) {
+    const int W = rp->width;
+    Counters *d_ctr = ctx->ctr.as<Counters>();
+    const dim3 grid_px((W + 15) / 16, owned), block(256);
+    const SPQueue q = sp_queue(ctx);
+    NodeEntry *tab = ctx->tab.as<NodeEntry>();
+    const uint32_t c_cap = ctx->c_cap, b_cap = ctx->b_cap;
+    const unsigned cus8 = 256 * 8;
+
+    HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+    HIPCHK(hipMemsetAsync(d_ctr, 0, sizeof(Counters), ctx->stream));
+    LAUNCH_SCENE(k_primary, grid_px, block, ctx, fp, d_pane, d_ctr, q, ctx->clist.as<uint32_t>(), ctx->groups.as<uint2>());
+    hipLaunchKernelGGL(k_mark_primary, dim3(1), dim3(64), 0, ctx->stream, d_ctr, q.cap);
+    HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+    LAUNCH_SCENE(k_secondary, dim3(std::min<unsigned>((c_cap + 255) / 256, 4096u)), block, ctx, fp, d_ctr, q, ctx->clist.as<uint32_t>(), c_cap, tab);
+    hipLaunchKernelGGL(k_mark_secondary, dim3(1), dim3(64), 0, ctx->stream, d_ctr, q.cap, b_cap);
+    HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+    // one lane per shadow ray; or (A/B switch) one lane per shade point with its 25 rays in sequence
+    if (ctx->shadow_per_ray) LAUNCH_SCENE(k_shadow_rays, dim3(std::min<unsigned>((q.cap + 9) / 10, 4 * cus8)), block, ctx, fp, q, d_ctr);
+    else LAUNCH_SCENE(k_shadow, dim3(std::min<unsigned>((q.cap + 255) / 256, 2 * cus8)), block, ctx, fp, q, d_ctr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+    // The gather: groups of neighbouring shade points first (k_gather_tile), then one wave per shade point for what
+    // the group kernel left and for the shade points of bounced pixels (k_gather).  Both kernels are launched with
+    // as many blocks as the device keeps resident and draw their work from device counters.
+    HIPCHK(hipMemsetAsync(ctx->sched.p, 0, 6 * SCHED_WORDS * 4, ctx->stream));   // 64 work counters per gather launch
+    uint32_t *sched = ctx->sched.as<uint32_t>();
+    uint32_t *left = ctx->left.as<uint32_t>();
+    const bool use_tiles = ctx->use_tiles;
+    const int dbg = getenv("PM_DEBUG") ? 1 : 0;
+    // The shade points of bounced pixels (slots n_sp0 .. n_sp0 + n_bounced) in spatial order, for the group kernel; queued
+    // before the wait for the maps, whose builds this overlaps.
+    const bool sort_bounced = use_tiles && ctx->group_bounced;
+    if (sort_bounced) {
+        HIPCHK(hipMemsetAsync(ctx->sp_bounds.p, 0xFF, 12, ctx->stream));                                   // minima
+        HIPCHK(hipMemsetAsync(ctx->sp_bounds.as<unsigned char>() + 12, 0, 12, ctx->stream));             // maxima
+        hipLaunchKernelGGL(k_sp_bounds, dim3(std::min(256u, (b_cap + 255) / 256)), block, 0, ctx->stream, q, d_ctr, ctx->sp_bounds.as<uint32_t>());
+        hipLaunchKernelGGL(k_sp_morton, dim3((b_cap + 255) / 256), block, 0, ctx->stream, q, d_ctr, ctx->sp_bounds.as<uint32_t>(),
+                           ctx->sp_keys_in.as<uint64_t>(), ctx->sp_vals_in.as<uint32_t>());
+        HIPCHK(radix_sort_pairs_30(ctx->stream, ctx->sp_keys_in.as<uint64_t>(), ctx->sp_vals_in.as<uint32_t>(), ctx->sp_keys_out.as<uint64_t>(),
+                                   ctx->sp_vals_out.as<uint32_t>(), ctx->sp_sort_tmp.as<uint32_t>(), b_cap, &d_ctr->n_bounced));
+        // cells of about six 63-NN radii (measured best on the default scene; most runs are then left to the tile kernel's own
+        // test of how far a group is spread): r^2 = 63 / (pi * density), density = photons / surface, surface taken as that
+        // of a cube over the points' extent (the sparser of the two maps decides)
+        long long n_ph = std::max<long long>(1, std::min(gmap ? gmap->n : (1LL << 40), cmap ? cmap->n : (1LL << 40)));
+        double cell_rel = ctx->sp_cell * sqrt(63.0 * 6.0 / (3.14159265 * (double)n_ph));
+        hipLaunchKernelGGL(k_sp_pieces, dim3((b_cap + 255) / 256), block, 0, ctx->stream, ctx->sp_keys_out.as<uint64_t>(), cell_rel, ctx->sp_pieces.as<uint2>(), d_ctr);
+        // one wave per piece
+        hipLaunchKernelGGL(k_sp_classify, dim3(std::min<unsigned>((b_cap + 3) / 4, 1024u)), block, 0, ctx->stream, q, ctx->sp_vals_out.as<uint32_t>(), ctx->sp_pieces.as<uint2>(),
+                           ctx->sp_bounds.as<uint32_t>(), (double)n_ph / 6.0, ctx->sp_est * (double)PM_TILE_EST_MAX, (uint32_t)ctx->sp_min_run,
+                           ctx->sp_groups.as<uint2>(), d_ctr, ctx->sp_early.as<uint32_t>());
+        HIPCHK(hipGetLastError());
+    }
+    const uint32_t *sorted = ctx->sp_vals_out.as<uint32_t>();
+    // what the group kernel does not take is the per-query kernel's range: everything without the group kernel, the
+    // bounced pixels' shade points when they are not grouped, else nothing but what the group kernel leaves
+    const int sec_mode = use_tiles ? (sort_bounced ? 0 : 1) : 2;
+    // Streams side by side, so that the thin end of one launch (few items left, most CUs idle) is filled by the others:
+    // the global map's groups on the caller's stream, the caustic map's groups on a second; each group kernel is followed,
+    // on its stream, by the per-query kernel for what it left.  A third stream carries the per-query gather of the bounced
+    // pixels' shade points that are not grouped.
+    HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+    HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+    HIPCHK(hipStreamWaitEvent(ctx->aux2, ctx->ev_fork, 0));
+    const uint32_t *zero = &d_ctr->pad;   // "nothing left": the third stream's launches have only the bounced range
+    // the map whose build is already over goes first
+    const bool global_late = gmap && gmap->pending && hipEventQuery(gmap->ready) != hipSuccess;
+    for (int turn = 0; turn < 2; turn++) {
+        const int kind = global_late ? 1 - turn : turn;
+        pm_map *map = kind == 0 ? gmap : cmap;
+        if (rp->flags & (kind == 0 ? PM_FLAG_NO_GLOBAL : PM_FLAG_NO_CAUSTIC)) continue;
+        hipStream_t st = kind == 0 ? ctx->stream : ctx->aux;
+        // the map may still be under construction on its build stream (beside the passes above, and beside the other
+        // map's gather): the gather's streams wait for it, the host does not
+        if (map->failed != PM_OK) return fail(map->failed, map->fail_msg);
+        if (map->pending) {
+            if (!ctx->yield_known[map->kind >= 0 ? map->kind : 0] && map->kind >= 0) PMCHK(map_ready(map));   // first map of a scene: is it complete at all?
+            else { HIPCHK(hipStreamWaitEvent(st, map->ready, 0)); HIPCHK(hipStreamWaitEvent(ctx->aux2, map->ready, 0)); }
+        }
+        uint32_t *lk = left + (size_t)kind * q.cap, *nl = &d_ctr->n_left[kind];
+        float4 *strips = ctx->strips.as<float4>() + (size_t)kind * ctx->tile_blocks * TS_STRIDE;
+        HIPCHK(hipEventRecord(ctx->ev_g[kind][0], st));
+        if (kind == 0) {
+            if (use_tiles) {
+                if (sec_mode == 1) hipLaunchKernelGGL(k_gather<0>, dim3(ctx->query_blocks), block, 0, ctx->aux2, map->view, q, lk, zero, d_ctr, 1, sched + 4 * SCHED_WORDS);
+                else hipLaunchKernelGGL(k_gather<0>, dim3(ctx->query_blocks), block, 0, ctx->aux2, map->view, q, ctx->sp_early.as<uint32_t>(), &d_ctr->n_early, d_ctr, 0, sched + 4 * SCHED_WORDS);
+                hipLaunchKernelGGL(k_gather_tile<0>, dim3(ctx->tile_blocks), dim3(64), 0, st, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sched, strips, dbg,
+                                   sorted, ctx->sp_groups.as<uint2>());
+            }
+            HIPCHK(hipEventRecord(ctx->ev_g[kind][1], st));
+            hipLaunchKernelGGL(k_gather<0>, dim3(ctx->query_blocks), block, 0, st, map->view, q, lk, nl, d_ctr, use_tiles ? 0 : 2, sched + SCHED_WORDS);
+        } else {
+            if (use_tiles) {
+                if (sec_mode == 1) hipLaunchKernelGGL(k_gather<1>, dim3(ctx->query_blocks), block, 0, ctx->aux2, map->view, q, lk, zero, d_ctr, 1, sched + 5 * SCHED_WORDS);
+                else hipLaunchKernelGGL(k_gather<1>, dim3(ctx->query_blocks), block, 0, ctx->aux2, map->view, q, ctx->sp_early.as<uint32_t>(), &d_ctr->n_early, d_ctr, 0, sched + 5 * SCHED_WORDS);
+                hipLaunchKernelGGL(k_gather_tile<1>, dim3(ctx->tile_blocks), dim3(64), 0, st, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sched + 2 * SCHED_WORDS, strips, dbg,
+                                   sorted, ctx->sp_groups.as<uint2>());
+            }
+            HIPCHK(hipEventRecord(ctx->ev_g[kind][1], st));
+            hipLaunchKernelGGL(k_gather<1>, dim3(ctx->query_blocks), block, 0, st, map->view, q, lk, nl, d_ctr, use_tiles ? 0 : 2, sched + 3 * SCHED_WORDS);
+        }
+        HIPCHK(hipEventRecord(ctx->ev_g[kind][2], st));
+        gathered[kind] = true;
+    }
+    HIPCHK(hipEventRecord(ctx->ev_join2, ctx->aux2));
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join2, 0));
+    HIPCHK(hipEventRecord(ctx->ev[4], ctx->stream));            // the global gather is done
+    HIPCHK(hipEventRecord(ctx->ev_join, ctx->aux));
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));            // both are done
+    LAUNCH_SCENE(k_shade, dim3(std::min<unsigned>((q.cap + 255) / 256, 2 * cus8)), block, ctx, fp, q, d_ctr, d_pane, tab);
+    LAUNCH_SCENE(k_resolve, dim3(std::min<unsigned>((c_cap + 255) / 256, cus8)), block, ctx, ctx->clist.as<uint32_t>(), d_ctr, c_cap, tab, d_pane);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev[6], ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, ctx->stream));
+    return PM_OK;
+}
+
 static int render_impl(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_params *rp, uint32_t *pane, int32_t pane_on_device, pm_stats *stats) {
     FrameParams fp;
     PMCHK(make_frame_params(ctx, rp, fp));
@@ -1015,173 +1140,74 @@ static int render_impl(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_
     if (stats) memset(stats, 0, sizeof(*stats));
     if (owned == 0) return PM_OK;
     const size_t owned_px = (size_t)owned * PM_ROW_BLOCK * W;
+    if (owned_px + owned_px / 4 > 0xFFFFFF00u) return fail(PM_EINVAL, "pm_render: too many pixels for one call; split the frame over more ranks");
 
     uint32_t *d_pane = pane;
     if (!pane_on_device) { PMCHK(ctx->pane.ensure((size_t)W * H * 4)); d_pane = ctx->pane.as<uint32_t>(); }
     PMCHK(ctx->ctr.ensure(sizeof(Counters)));
     PMCHK(ctx->clist.ensure(owned_px * 4));
     PMCHK(ctx->groups.ensure((size_t)owned * 2 * ((W + 7) / 8) * sizeof(uint2)));   // one group per 8x8 pixel tile: 2 tile rows per row block, ceil(W/8) columns
-    PMCHK(ensure_sp(ctx, (uint32_t)std::min<size_t>(owned_px + owned_px / 4, 0xFFFFFF00u)));
-    Counters *d_ctr = ctx->ctr.as<Counters>();
-    dim3 grid_px((W + 15) / 16, owned), block(256);
-
-    HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
-    uint32_t n_sp0 = 0, n_complex = 0;
-    for (int attempt = 0; attempt < 2; attempt++) {
-        HIPCHK(hipMemsetAsync(d_ctr, 0, sizeof(Counters), ctx->stream));
-        SPQueue q = sp_queue(ctx);
-        LAUNCH_SCENE(k_primary, grid_px, block, ctx, fp, d_pane, d_ctr, q, ctx->clist.as<uint32_t>(), ctx->groups.as<uint2>());
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(ctx->h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        n_sp0 = ctx->h_ctr->n_sp; n_complex = ctx->h_ctr->n_complex;
-        if (ctx->h_ctr->overflow && getenv("PM_SP_CAP_LIMIT")) return fail(PM_ESTATE, "pm_render: the shade point queue overflowed (" + std::to_string(ctx->h_ctr->n_sp) + " shade points): the pane is incomplete");
-        size_t need = (size_t)n_sp0 + (size_t)15 * n_complex;   // every node of a bounced pixel's tree may absorb
-        if (need > 0xFFFFFF00u) return fail(PM_EINVAL, "pm_render: too many shade points for one call; split the frame over more ranks");
-        if (need <= ctx->sp_cap) break;
-        PMCHK(ensure_sp(ctx, (uint32_t)need));   // queues were reallocated: run the primary pass again
-    }
-    HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
-    uint32_t n_sp = n_sp0, n_secondary = 0;
-    SPQueue q = sp_queue(ctx);
-    NodeEntry *tab = nullptr;
-    if (n_complex) {
-        PMCHK(ctx->tab.ensure((size_t)n_complex * 16 * sizeof(NodeEntry)));
-        tab = ctx->tab.as<NodeEntry>();
-        LAUNCH_SCENE(k_secondary, dim3((n_complex + 255) / 256), block, ctx, fp, d_ctr, q, ctx->clist.as<uint32_t>(), n_complex, tab);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(ctx->h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        n_sp = ctx->h_ctr->n_sp; n_secondary = ctx->h_ctr->n_secondary;
-        if (ctx->h_ctr->overflow) return fail(PM_ESTATE, "pm_render: the shade point queue overflowed (" + std::to_string(ctx->h_ctr->n_sp) + " shade points): the pane is incomplete");
-    }
-    HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
-    int n_gathers = 0;
+    PMCHK(gather_blocks(ctx));
+    PMCHK(ctx->sched.ensure(6 * SCHED_WORDS * 4 + 2 * 8192 * 16));
+    PMCHK(ctx->strips.ensure((size_t)2 * ctx->tile_blocks * TS_STRIDE * sizeof(float4)));
+    PMCHK(ctx->sp_bounds.ensure(6 * 4));
+    // Capacities the frame is launched for.  They start from what frames of this size usually need and only grow: a frame
+    // that needed more says so (Counters::overflow) and is rendered again with what it asked for.
+    uint32_t want_sp = (uint32_t)(owned_px + owned_px / 4), want_c = (uint32_t)(owned_px / 8 + 4096), want_b = (uint32_t)(owned_px / 8 + 4096);
     bool gathered[2] = {false, false};
-    uint32_t n_primary_sp = 0, n_sorted = 0;
-    if (n_sp) {
-        // one lane per shadow ray; or (A/B switch) one lane per shade point with its 25 rays in sequence
-        if (ctx->shadow_per_ray) LAUNCH_SCENE(k_shadow_rays, dim3((n_sp + 9) / 10), block, ctx, fp, q, n_sp);
-        else LAUNCH_SCENE(k_shadow, dim3((n_sp + 255) / 256), block, ctx, fp, q, n_sp);
-        HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
-        // The gather: groups of neighbouring shade points first (k_gather_tile), then one wave per shade point for what
-        // the group kernel left and for the shade points of bounced pixels (k_gather).  Both kernels are launched with
-        // as many blocks as the device keeps resident and draw their work from device counters.
-        PMCHK(gather_blocks(ctx));
-        PMCHK(ctx->sched.ensure(6 * SCHED_WORDS * 4 + 2 * 8192 * 16));
-        PMCHK(ctx->left.ensure((size_t)2 * n_sp * 4 + 8));
-        PMCHK(ctx->strips.ensure((size_t)2 * ctx->tile_blocks * TS_STRIDE * sizeof(float4)));
-        HIPCHK(hipMemsetAsync(ctx->sched.p, 0, 6 * SCHED_WORDS * 4, ctx->stream));   // 64 work counters per gather launch
-        uint32_t *sched = ctx->sched.as<uint32_t>();
-        uint32_t *left = ctx->left.as<uint32_t>();
-        const bool use_tiles = ctx->use_tiles && n_sp0 > 0;
-        const int dbg = getenv("PM_DEBUG") ? 1 : 0;
-        // The shade points of bounced pixels (slots n_sp0 .. n_sp) in spatial order, for the group kernel; queued before the
-        // wait for the maps, whose builds this overlaps.
-        const bool sort_bounced = use_tiles && ctx->group_bounced && n_sp > n_sp0;
-        n_sorted = sort_bounced ? n_sp - n_sp0 : 0u;
-        if (sort_bounced) {
-            PMCHK(ctx->sp_keys_in.ensure((size_t)n_sorted * 8)); PMCHK(ctx->sp_keys_out.ensure((size_t)n_sorted * 8));
-            PMCHK(ctx->sp_vals_in.ensure((size_t)n_sorted * 4)); PMCHK(ctx->sp_vals_out.ensure((size_t)n_sorted * 4));
-            PMCHK(ctx->sp_bounds.ensure(6 * 4));
-            HIPCHK(hipMemsetAsync(ctx->sp_bounds.p, 0xFF, 12, ctx->stream));                                   // minima
-            HIPCHK(hipMemsetAsync(ctx->sp_bounds.as<unsigned char>() + 12, 0, 12, ctx->stream));             // maxima
-            hipLaunchKernelGGL(k_sp_bounds, dim3(std::min(256u, (n_sorted + 255) / 256)), block, 0, ctx->stream, q, n_sp0, n_sorted, ctx->sp_bounds.as<uint32_t>());
-            hipLaunchKernelGGL(k_sp_morton, dim3((n_sorted + 255) / 256), block, 0, ctx->stream, q, n_sp0, n_sorted, ctx->sp_bounds.as<uint32_t>(),
-                               ctx->sp_keys_in.as<uint64_t>(), ctx->sp_vals_in.as<uint32_t>());
-            PMCHK(ctx->sp_sort_tmp.ensure(sort_scratch_words(n_sorted) * 4));
-            HIPCHK(radix_sort_pairs_30(ctx->stream, ctx->sp_keys_in.as<uint64_t>(), ctx->sp_vals_in.as<uint32_t>(), ctx->sp_keys_out.as<uint64_t>(),
-                                       ctx->sp_vals_out.as<uint32_t>(), ctx->sp_sort_tmp.as<uint32_t>(), n_sorted, nullptr));
-            // cells of about six 63-NN radii (measured best on the default scene; most runs are then left to the tile kernel's own
-            // test of how far a group is spread): r^2 = 63 / (pi * density), density = photons / surface, surface taken as that
-            // of a cube over the points' extent (the sparser of the two maps decides)
-            long long n_ph = std::max<long long>(1, std::min(gmap ? gmap->n : (1LL << 40), cmap ? cmap->n : (1LL << 40)));
-            double cell_rel = ctx->sp_cell * sqrt(63.0 * 6.0 / (3.14159265 * (double)n_ph));
-            PMCHK(ctx->sp_groups.ensure((size_t)n_sorted * sizeof(uint2)));
-            PMCHK(ctx->sp_early.ensure((size_t)n_sorted * 4));
-            PMCHK(ctx->sp_pieces.ensure((size_t)n_sorted * sizeof(uint2)));
-            hipLaunchKernelGGL(k_sp_pieces, dim3((n_sorted + 255) / 256), block, 0, ctx->stream, ctx->sp_keys_out.as<uint64_t>(), n_sorted, cell_rel, ctx->sp_pieces.as<uint2>(), d_ctr);
-            // one wave per piece; at most one piece per min(64, run) points, launched for the worst case of one piece per point
-            hipLaunchKernelGGL(k_sp_classify, dim3((n_sorted + 3) / 4), block, 0, ctx->stream, q, ctx->sp_vals_out.as<uint32_t>(), ctx->sp_pieces.as<uint2>(),
-                               ctx->sp_bounds.as<uint32_t>(), (double)n_ph / 6.0, ctx->sp_est * (double)PM_TILE_EST_MAX, (uint32_t)ctx->sp_min_run,
-                               ctx->sp_groups.as<uint2>(), d_ctr, ctx->sp_early.as<uint32_t>());
+    for (int attempt = 0;; attempt++) {
+        PMCHK(ensure_sp(ctx, want_sp));
+        PMCHK(ctx->left.ensure((size_t)2 * ctx->sp_cap * 4 + 8));
+        if (want_c > ctx->c_cap) { PMCHK(ctx->tab.ensure((size_t)want_c * 16 * sizeof(NodeEntry))); ctx->c_cap = want_c; }
+        if (want_b > ctx->b_cap) {
+            PMCHK(ctx->sp_keys_in.ensure((size_t)want_b * 8)); PMCHK(ctx->sp_keys_out.ensure((size_t)want_b * 8));
+            PMCHK(ctx->sp_vals_in.ensure((size_t)want_b * 4)); PMCHK(ctx->sp_vals_out.ensure((size_t)want_b * 4));
+            PMCHK(ctx->sp_sort_tmp.ensure(sort_scratch_words(want_b) * 4));
+            PMCHK(ctx->sp_groups.ensure((size_t)want_b * sizeof(uint2))); PMCHK(ctx->sp_early.ensure((size_t)want_b * 4)); PMCHK(ctx->sp_pieces.ensure((size_t)want_b * sizeof(uint2)));
+            ctx->b_cap = want_b;
         }
-        const uint32_t *sorted = ctx->sp_vals_out.as<uint32_t>();
-        n_primary_sp = use_tiles ? n_sp0 + n_sorted : 0u;
-        // what the group kernel does not take is the per-query kernel's range: everything without the group kernel, the
-        // bounced pixels' shade points when they are not grouped, else nothing but what the group kernel leaves
-        const uint32_t sec_lo = use_tiles ? n_sp0 : 0u, sec_n = sort_bounced ? 0u : n_sp - sec_lo;
-        // Streams side by side, so that the thin end of one launch (few items left, most CUs idle) is filled by the others:
-        // the global map's groups on the caller's stream, the caustic map's groups on a second; each group kernel is followed,
-        // on its stream, by the per-query kernel for what it left.  A third stream carries the per-query gather of the bounced
-        // pixels' shade points for both maps when those are not grouped (PM_GROUP_BOUNCED=0).
-        HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
-        HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
-        HIPCHK(hipStreamWaitEvent(ctx->aux2, ctx->ev_fork, 0));
-        const uint32_t *zero = &d_ctr->pad;   // "nothing left": the third stream's launches have only the bounced range
-        // the map whose build is already over goes first
-        const bool global_late = gmap && gmap->pending && hipEventQuery(gmap->ready) != hipSuccess;
-        for (int turn = 0; turn < 2; turn++) {
-            const int kind = global_late ? 1 - turn : turn;
+        gathered[0] = gathered[1] = false;
+        PMCHK(enqueue_frame(ctx, gmap, cmap, rp, fp, d_pane, owned, gathered));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        const Counters &hc = *ctx->h_ctr;
+        bool again = false;
+        if (hc.overflow) {
+            if (getenv("PM_SP_CAP_LIMIT") || attempt >= 3)
+                return fail(PM_ESTATE, "pm_render: the shade point queue overflowed (" + std::to_string(hc.n_sp) + " shade points): the pane is incomplete");
+            if (hc.n_sp > 0xFFFFFF00u) return fail(PM_EINVAL, "pm_render: too many shade points for one call; split the frame over more ranks");
+            // the counters kept counting past the capacities: they say what the frame needs
+            if (hc.overflow & OVF_SP) want_sp = std::max(want_sp, hc.n_sp);
+            if (hc.overflow & OVF_COMPLEX) { want_c = hc.n_complex + hc.n_complex / 8; want_sp = std::max<uint64_t>(want_sp, std::min<uint64_t>((uint64_t)hc.n_sp + 15ull * (hc.n_complex - ctx->c_cap), 0xFFFFFF00u)); }
+            if (hc.overflow & OVF_BOUNCED) want_b = (hc.n_sp - hc.n_sp0) + (hc.n_sp - hc.n_sp0) / 8;
+            again = true;
+        }
+        // the maps the streams waited for: did their one emission range hold n photons?  (a scene that stores far fewer photons
+        // per attempt than the last map of this scene did: topped up and indexed again here, and the frame is rendered again)
+        for (int kind = 0; kind < 2; kind++) {
             pm_map *map = kind == 0 ? gmap : cmap;
-            if (rp->flags & (kind == 0 ? PM_FLAG_NO_GLOBAL : PM_FLAG_NO_CAUSTIC)) continue;
-            // the map may still be under construction on its build stream (beside the passes above, and beside the other
-            // map's gather): wait for it here
-            PMCHK(map_ready(map));
-            hipStream_t st = kind == 0 ? ctx->stream : ctx->aux;
-            uint32_t *lk = left + (size_t)kind * n_sp, *nl = &d_ctr->n_left[kind];
-            float4 *strips = ctx->strips.as<float4>() + (size_t)kind * ctx->tile_blocks * TS_STRIDE;
-            HIPCHK(hipEventRecord(ctx->ev_g[kind][0], st));
-            if (kind == 0) {
-                if (use_tiles) {
-                    if (sec_n) hipLaunchKernelGGL(k_gather<0>, dim3(ctx->query_blocks), block, 0, ctx->aux2, map->view, q, lk, zero, sec_lo, sec_n, sched + 4 * SCHED_WORDS);
-                    else if (n_sorted) hipLaunchKernelGGL(k_gather<0>, dim3(ctx->query_blocks), block, 0, ctx->aux2, map->view, q, ctx->sp_early.as<uint32_t>(), &d_ctr->n_early, 0u, 0u, sched + 4 * SCHED_WORDS);
-                    hipLaunchKernelGGL(k_gather_tile<0>, dim3(ctx->tile_blocks), dim3(64), 0, st, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sched, strips, dbg,
-                                       sorted, ctx->sp_groups.as<uint2>());
-                }
-                HIPCHK(hipEventRecord(ctx->ev_g[kind][1], st));
-                hipLaunchKernelGGL(k_gather<0>, dim3(ctx->query_blocks), block, 0, st, map->view, q, lk, nl, sec_lo, use_tiles ? 0u : sec_n, sched + SCHED_WORDS);
-            } else {
-                if (use_tiles) {
-                    if (sec_n) hipLaunchKernelGGL(k_gather<1>, dim3(ctx->query_blocks), block, 0, ctx->aux2, map->view, q, lk, zero, sec_lo, sec_n, sched + 5 * SCHED_WORDS);
-                    else if (n_sorted) hipLaunchKernelGGL(k_gather<1>, dim3(ctx->query_blocks), block, 0, ctx->aux2, map->view, q, ctx->sp_early.as<uint32_t>(), &d_ctr->n_early, 0u, 0u, sched + 5 * SCHED_WORDS);
-                    hipLaunchKernelGGL(k_gather_tile<1>, dim3(ctx->tile_blocks), dim3(64), 0, st, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sched + 2 * SCHED_WORDS, strips, dbg,
-                                       sorted, ctx->sp_groups.as<uint2>());
-                }
-                HIPCHK(hipEventRecord(ctx->ev_g[kind][1], st));
-                hipLaunchKernelGGL(k_gather<1>, dim3(ctx->query_blocks), block, 0, st, map->view, q, lk, nl, sec_lo, use_tiles ? 0u : sec_n, sched + 3 * SCHED_WORDS);
-            }
-            HIPCHK(hipEventRecord(ctx->ev_g[kind][2], st));
-            gathered[kind] = true;
-            n_gathers++;
+            if (!gathered[kind] || !map) continue;
+            bool rebuilt = false;
+            PMCHK(map_ready(map, &rebuilt));
+            again = again || rebuilt;
         }
-        HIPCHK(hipEventRecord(ctx->ev_join2, ctx->aux2));
-        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join2, 0));
-        HIPCHK(hipEventRecord(ctx->ev[4], ctx->stream));            // the global gather is done
-        HIPCHK(hipEventRecord(ctx->ev_join, ctx->aux));
-        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-        HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));            // both are done
-        LAUNCH_SCENE(k_shade, dim3((n_sp + 255) / 256), block, ctx, fp, q, n_sp, d_pane, tab);
-    } else {
-        for (int i = 3; i <= 5; i++) HIPCHK(hipEventRecord(ctx->ev[i], ctx->stream));
+        if (!again) break;
     }
-    if (n_complex) LAUNCH_SCENE(k_resolve, dim3((n_complex + 255) / 256), block, ctx, ctx->clist.as<uint32_t>(), n_complex, tab, d_pane);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(ctx->ev[6], ctx->stream));
     if (!pane_on_device) {
         for (int b = rp->rank; b < nblk; b += rp->world) {
             size_t y0 = (size_t)b * PM_ROW_BLOCK, y1 = std::min<size_t>(y0 + PM_ROW_BLOCK, (size_t)H);
             HIPCHK(hipMemcpyAsync(pane + y0 * W, d_pane + y0 * W, (y1 - y0) * W * 4, hipMemcpyDeviceToHost, ctx->stream));
         }
+        HIPCHK(hipStreamSynchronize(ctx->stream));
     }
-    HIPCHK(hipMemcpyAsync(ctx->h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (ctx->h_ctr->overflow) return fail(PM_ESTATE, "pm_render: the shade point queue overflowed (" + std::to_string(ctx->h_ctr->n_sp) + " shade points): the pane is incomplete");
+    const Counters hc = *ctx->h_ctr;
+    const uint32_t n_sp0 = hc.n_sp0, n_sp = hc.n_sp0 + hc.n_bounced, n_complex = hc.n_complex, n_secondary = hc.n_secondary;
+    const bool sort_bounced = ctx->use_tiles && ctx->group_bounced;
+    const uint32_t n_sorted = sort_bounced ? hc.n_bounced : 0u, n_primary_sp = ctx->use_tiles ? n_sp0 + n_sorted : 0u;
+    const int n_gathers = (gathered[0] ? 1 : 0) + (gathered[1] ? 1 : 0);
+    Counters *d_ctr = ctx->ctr.as<Counters>();
     if (getenv("PM_DEBUG")) {
-        Counters hc;
-        if (hipMemcpy(&hc, d_ctr, sizeof(hc), hipMemcpyDeviceToHost) == hipSuccess)
-            fprintf(stderr, "[pm] shade points %u (primary %u), groups %u, left to the per-query gather: global %u caustic %u\n", hc.n_sp, n_sp0,
-                    hc.n_groups, hc.n_left[0], hc.n_left[1]);
+        fprintf(stderr, "[pm] shade points %u (primary %u), groups %u, left to the per-query gather: global %u caustic %u\n", n_sp, n_sp0,
+                hc.n_groups, hc.n_left[0], hc.n_left[1]);
         fprintf(stderr, "[pm] bounced pixels' shade points in spatial order: %u, in %u groups; %u straight to the per-query kernel\n", n_sorted, hc.n_sgroups, hc.n_early);
         fprintf(stderr, "[pm] lanes handed over, by reason (few photons, spread, radius, |S|, no lane served, -, own shortfall): %u %u %u %u %u %u %u\n", hc.why[1], hc.why[2],
                 hc.why[3], hc.why[4], hc.why[5], hc.why[6], hc.why[7]);
@@ -1193,6 +1219,7 @@ static int render_impl(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_
         fprintf(stderr, "[pm] group kernel ticks per phase (centre query, collect, pass 1, pass 2, rank, sum): %llu %llu %llu %llu %llu %llu; shared sets %llu, candidates %llu\n", hc.tphase[0],
                 hc.tphase[1], hc.tphase[2], hc.tphase[3], hc.tphase[4], hc.tphase[5], hc.tphase[7], hc.tphase[6]);
     }
+    (void)d_ctr;
 #ifdef PM_WAVE_TIMES
     if (const char *path = getenv("PM_WAVE_DUMP")) {
         std::vector<uint32_t> h(2 * 8192 * 4);
@@ -1215,12 +1242,12 @@ static int render_impl(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_
         if (gathered[0]) {
             (void)hipEventElapsedTime(&stats->ms_gather_global, ctx->ev_g[0][0], ctx->ev_g[0][2]);
             (void)hipEventElapsedTime(&stats->ms_group_global, ctx->ev_g[0][0], ctx->ev_g[0][1]);
-            stats->grouped_global = n_primary_sp ? n_primary_sp - ctx->h_ctr->n_left[0] - ctx->h_ctr->n_early : 0u;
+            stats->grouped_global = n_primary_sp ? n_primary_sp - hc.n_left[0] - hc.n_early : 0u;
         }
         if (gathered[1]) {
             (void)hipEventElapsedTime(&stats->ms_gather_caustic, ctx->ev_g[1][0], ctx->ev_g[1][2]);
             (void)hipEventElapsedTime(&stats->ms_group_caustic, ctx->ev_g[1][0], ctx->ev_g[1][1]);
-            stats->grouped_caustic = n_primary_sp ? n_primary_sp - ctx->h_ctr->n_left[1] - ctx->h_ctr->n_early : 0u;
+            stats->grouped_caustic = n_primary_sp ? n_primary_sp - hc.n_left[1] - hc.n_early : 0u;
         }
         (void)hipEventElapsedTime(&stats->ms_resolve, ctx->ev[5], ctx->ev[6]);
         (void)hipEventElapsedTime(&stats->ms_total, ctx->ev[0], ctx->ev[6]);

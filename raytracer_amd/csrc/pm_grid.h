@@ -33,6 +33,12 @@ constexpr int GRID_MAX_LEVEL = 10;   // cells are not split below this level: ph
 #ifndef PM_GRID_MULTI
 #define PM_GRID_MULTI 4        // big cells split per round once lim is an actual k-th distance
 #endif
+#ifndef PM_BLOCK_MIN
+#define PM_BLOCK_MIN 24        // block query: the level whose cell around the query holds at least this many photons ...
+#endif
+#ifndef PM_BLOCK_MAX
+#define PM_BLOCK_MAX 1536      // ... and whose 3x3x3 block holds at most this many (a dense cluster next door: the walk prunes it, the block cannot)
+#endif
 
 // photon range [first, first + cnt) of the cell with Morton key `key` at `level`; below the finest table the
 // cell is a sub-range of [plo, pend) (its parent's range): two binary searches on the sorted keys
@@ -151,6 +157,68 @@ __device__ inline void grid_scan(KnnState &st, const MapView &m, const V3 &q, bo
     }
 }
 
+// Block query: the common case answered without a walk.  A query that lies among photons (a shade point on a lit surface)
+// finds its 63 neighbours inside the 3x3x3 block of cells around it at the level where a cell is about as wide as the 63rd
+// distance.  One round of table lookups picks that level (the finest one whose cell around the query holds PM_BLOCK_MIN
+// photons) and the block's 27 ranges, one scan reads them, one reduce selects.  The answer is exact whenever the 63rd
+// distance turns out smaller than the distance m from the query to the nearest face of the block beyond which photons can
+// lie: every photon outside the block is at least m away, and every photon of the block closer than m was offered.
+// Returns false when it does not apply or did not succeed (fewer than 63 photons within m): the walk below then answers,
+// from scratch.
+__device__ inline bool block_query(KnnState &st, const MapView &m, const V3 &q, const uint32_t qf[3]) {
+    const int lane = st.lane;
+    const int L = m.lmax;
+    if (L < 1) return false;
+    const double qa[3] = {q.x, q.y, q.z};
+    // the query must lie inside the grid (its fine coordinates are clamped otherwise and say nothing about distances)
+    for (int a = 0; a < 3; a++) if (!(qa[a] >= (double)m.glo[a] && qa[a] <= (double)m.glo[a] + (double)m.gext)) return false;
+    // photons in the query's own cell, level by level (lane l: level l)
+    uint32_t first = 0, cnt = 0;
+    if (lane >= 1 && lane <= L) {
+        const int sh = 21 - lane;
+        cell_range(m, lane, cell_key(lane, qf[0] >> sh, qf[1] >> sh, qf[2] >> sh), 0u, 0u, first, cnt);
+    }
+    const unsigned long long enough = __ballot(lane >= 1 && lane <= L && cnt >= (uint32_t)PM_BLOCK_MIN);
+    if (enough == 0ULL) return false;
+    const int lev = 63 - __clzll((long long)enough);     // the finest such level
+    const int sh = 21 - lev;
+    const uint32_t side = 1u << lev;
+    const uint32_t c0[3] = {qf[0] >> sh, qf[1] >> sh, qf[2] >> sh};
+    // distance to the nearest face of the block that has cells beyond it (the grid's own faces have nothing beyond them),
+    // less the binning margin of cell_d2
+    double mdist = __builtin_inf();
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        if (c0[a] > 0u) mdist = fmin(mdist, qa[a] - ((double)m.glo[a] + (double)((c0[a] - 1u) << sh) * m.gu));
+        if (c0[a] + 1u < side) mdist = fmin(mdist, ((double)m.glo[a] + (double)((c0[a] + 2u) << sh) * m.gu) - qa[a]);
+    }
+    mdist -= 3.0 * m.gu;
+    if (!(mdist > 0.0)) return false;
+    const double lim = fmin(mdist * mdist, MAX_R2);
+    // the block's cells, one per lane
+    first = 0; cnt = 0;
+    double dmin2 = 0.0, dmax2 = 0.0;
+    if (lane < 27) {
+        const int dx = lane % 3 - 1, dy = (lane / 3) % 3 - 1, dz = lane / 9 - 1;
+        const uint32_t cx = c0[0] + (uint32_t)dx, cy = c0[1] + (uint32_t)dy, cz = c0[2] + (uint32_t)dz;   // wraps below zero: caught by the test
+        if (cx < side && cy < side && cz < side) {
+            const uint64_t key = cell_key(lev, cx, cy, cz);
+            cell_range(m, lev, key, 0u, 0u, first, cnt);
+            if (cnt > 0) { cell_d2(m, q, q, lev, cx, cy, cz, key, true, dmin2, dmax2); if (!(dmin2 < lim)) cnt = 0; }
+        }
+    }
+    uint32_t total = wave_scan_incl_u32(cnt);
+    total = (uint32_t)__builtin_amdgcn_readlane((int)total, 63);
+    if (total < (uint32_t)KNN_K || total > (uint32_t)PM_BLOCK_MAX) return false;
+    st.lim = lim;
+    st.count = 0;
+    st.reduced = false;
+    grid_scan(st, m, q, cnt > 0, first, cnt);
+    if (st.count < KNN_K) { st.count = 0; return false; }
+    if (st.count > KNN_K || !st.reduced) knn_reduce(st);
+    return true;      // st.lim is the exact 63rd distance, below m^2 by construction of the scan
+}
+
 // Full query; same contract as knn_query (pm_knn.h).
 // lim0: a proven bound on the 63rd-smallest d2 (63 photons or more lie closer than it), or MAX_R2 when nothing is
 // known.  Runs of neighbouring queries pass (sqrt(r_prev) + |q - q_prev|)^2: the previous ball lies inside that one.
@@ -170,6 +238,12 @@ __device__ inline int grid_query(KnnState &st, KnnBuf *buf, const MapView &m, co
     r = 0.0;
     if (m.n <= 0) return 0;
     const uint32_t qf[3] = {quant21((float)q.x, m.glo[0], m.gext), quant21((float)q.y, m.glo[1], m.gext), quant21((float)q.z, m.glo[2], m.gext)};
+#ifndef PM_NO_BLOCK_QUERY
+    if (block_query(st, m, q, qf)) { st.c_nodes = 0x80000000u; wave_lds_fence(); r = st.lim; return st.count; }   // (work counters: the top bit of `nodes` says the block query answered)
+    st.lim = fmin(lim0, MAX_R2);
+    st.count = 0;
+    st.reduced = false;
+#endif
     // The queue, one cell per lane: lanes 7(l-1) .. 7(l-1)+6 hold the 7 siblings of the query's level-l cell, lane 7*lmax
     // the query's own cell at level lmax.  Together they tile the whole grid (lmax <= 8: 57 lanes).
     const int L = m.lmax;

@@ -29,8 +29,18 @@ struct FrameParams {
     int rank, world;
 };
 
-struct Counters { uint32_t n_sp, n_complex, n_secondary, n_groups, n_left[2], pad, n_sgroups, n_early, n_pieces, overflow; uint32_t why[8]; unsigned long long tphase[8]; uint32_t ghist[2][32]; };   // n_left[k]: shade points left to the per-query gather of map k
+struct Counters { uint32_t n_sp, n_complex, n_secondary, n_groups, n_left[2], pad, n_sgroups, n_early, n_pieces, overflow, n_sp0, n_bounced, done_primary, done_secondary; uint32_t why[8]; unsigned long long tphase[8]; uint32_t ghist[2][32]; };   // n_left[k]: shade points left to the per-query gather of map k
 
+// The frame's counts live on the device: nothing of a frame waits for the host.  n_sp0 = shade points of primary hits (slots
+// 0 .. n_sp0, grouped by pixel tile), written by k_mark_primary behind k_primary; n_bounced = shade points of bounced pixels
+// (slots n_sp0 .. n_sp0 + n_bounced), written by k_mark_secondary behind k_secondary.  Every later kernel is launched for the
+// capacity of the queues and reads what there really is from here.  overflow: bit 0 = a shade point did not fit, bit 1 = more
+// bounced pixels than node tables, bit 2 = more bounced pixels' shade points than the spatial sort was sized for; the host
+// looks at it once, when the frame is over, grows what was too small and renders the frame again.
+enum { OVF_SP = 1u, OVF_COMPLEX = 2u, OVF_BOUNCED = 4u };
+__device__ inline uint32_t sp_total(const Counters *ctr, uint32_t cap) { return min(ctr->n_sp0 + ctr->n_bounced, cap); }
+// (A counter of finished blocks would let the last block of k_primary write n_sp0 itself, but 8 100 blocks adding to one
+// address serialise at about 90 ns each: 0.7 ms.  Two one-wave kernels between the passes cost 5 us each.)
 // shade point queue (SoA)
 struct SPQueue {
     double *geo;         // [6][cap]: px py pz nx ny nz
@@ -69,7 +79,7 @@ __device__ inline uint32_t mix_colour(uint32_t reflect_res, uint32_t refract_res
 __device__ inline void sp_store(const SPQueue &q, uint32_t slot, const V3 &res, const V3 &nrm, int obj, uint32_t pixel, uint32_t node, uint32_t tabslot) {
     // capacity is sized for the worst case on the host; should it ever not be, the frame is reported as failed (PM_ESTATE)
     // rather than delivered with pixels missing
-    if (slot >= q.cap) { *q.overflow = 1u; return; }
+    if (slot >= q.cap) { atomicOr(q.overflow, (uint32_t)OVF_SP); return; }
     q.geo[0 * (size_t)q.cap + slot] = res.x; q.geo[1 * (size_t)q.cap + slot] = res.y; q.geo[2 * (size_t)q.cap + slot] = res.z;
     q.geo[3 * (size_t)q.cap + slot] = nrm.x; q.geo[4 * (size_t)q.cap + slot] = nrm.y; q.geo[5 * (size_t)q.cap + slot] = nrm.z;
     q.obj[slot] = obj; q.pixel[slot] = pixel; q.node[slot] = node; q.tabslot[slot] = tabslot;
@@ -128,6 +138,16 @@ __global__ __launch_bounds__(256) void k_primary(SceneView gs, FrameParams fp, u
         if (emit_cx) complex_list[base + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL))] = pixel;
     }
 }
+// the counts of the pass that just ended, for the kernels behind it (one thread)
+__global__ void k_mark_primary(Counters *ctr, uint32_t cap) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) ctr->n_sp0 = min(ctr->n_sp, cap);
+}
+__global__ void k_mark_secondary(Counters *ctr, uint32_t cap, uint32_t b_cap) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t total = min(ctr->n_sp, cap), nb = total - ctr->n_sp0;
+    if (nb > b_cap) atomicOr(&ctr->overflow, (uint32_t)OVF_BOUNCED);
+    ctr->n_bounced = min(nb, b_cap);     // what the kernels behind may touch; the flag has the frame rendered again
+}
 
 // hit ids / points / normals only (parity gate for primary rays)
 template <int MODE>
@@ -155,119 +175,124 @@ struct NodeEntry { uint32_t a, b; };
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_secondary(SceneView gs, FrameParams fp, Counters *ctr, SPQueue q, const uint32_t *complex_list,
-                                                    uint32_t n_complex, NodeEntry *tab) {
+                                                    uint32_t c_cap, NodeEntry *tab) {
     extern __shared__ __align__(16) unsigned char smem[];
     SceneView sv = gs;
     if (MODE == SCENE_LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
-    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_complex) return;
-    uint32_t pixel = complex_list[c];
-    int x = (int)(pixel % (uint32_t)fp.width), y = (int)(pixel / (uint32_t)fp.width);
-    NodeEntry *my = tab + (size_t)c * 16;
-    for (int i = 0; i < 16; i++) { my[i].a = 0; my[i].b = 0; }
+    // launched for the capacity of the node tables; the number of bounced pixels is on the device
+    uint32_t n_complex = ctr->n_complex;
+    if (n_complex > c_cap) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(&ctr->overflow, (uint32_t)OVF_COMPLEX); n_complex = c_cap; }
+    uint32_t nsec = 0;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n_complex; c += gridDim.x * blockDim.x) {
+        uint32_t pixel = complex_list[c];
+        int x = (int)(pixel % (uint32_t)fp.width), y = (int)(pixel / (uint32_t)fp.width);
+        NodeEntry *my = tab + (size_t)c * 16;
+        for (int i = 0; i < 16; i++) { my[i].a = 0; my[i].b = 0; }
 
-    struct Frame { V3 hit, nrm; int obj; int stage; };
-    Frame fr[4];
-    V3 src = fp.cam;
-    V3 ray = primary_ray(fp.width, fp.height, fp.cam, fp.K, pixel, x, y);
-    int depth = 0, exclude = -1;
-    uint32_t node = 1, nsec = 0;
-    for (;;) {
-        // ---- enter traceRay(src, ray, exclude, bounce = depth) : src/Raytrace.cpp:32-47
-        bool returned = false;
-        if (depth > 3) returned = true;   // bounce > MAX_BOUNCES: opaque black, no draw, no table entry
-        else {
-            double dt = draw(item_key(fp.K, (uint64_t)pixel * 32u + node), 0);
-            if (depth > 0) nsec++;
-            V3 res = {0, 0, 0}, nrm = {0, 0, 0};
-            int obj = scene_intersect<MODE>(sv, src, ray, exclude, dt, res, nrm);
-            if (obj < 0) { my[node].a = 1; my[node].b = 0xFF000000u; returned = true; }
-            else if (is_light_patch(res)) { my[node].a = 1; my[node].b = light_colour(fp.light); returned = true; }
-            else { fr[depth].hit = res; fr[depth].nrm = nrm; fr[depth].obj = obj; fr[depth].stage = 0; }
-        }
-        if (returned) { depth--; node >>= 1; }
-        // ---- resume frames until one of them makes a recursive call
-        bool descend = false;
-        while (depth >= 0 && !descend) {
-            Frame &f = fr[depth];
-            int obj = f.obj;
-            if (f.stage == 0) {
-                f.stage = 1;
-                if (sv.f(G_TRANSMISSION, obj) > 0) {   // refract, src/Raytrace.cpp:52-71
-                    double n = 1 / sv.f(G_REFRACTION, obj);
-                    double d = f.nrm.x * ray.x + f.nrm.y * ray.y + f.nrm.z * ray.z;
-                    V3 n1 = {f.nrm.x * d, f.nrm.y * d, f.nrm.z * d};
-                    n1.x = ray.x - n1.x; n1.y = ray.y - n1.y; n1.z = ray.z - n1.z;
-                    n1.x *= n; n1.y *= n; n1.z *= n;
-                    double s = 1 - (n * n) * (1 - d * d);
-                    double sq = sqrt(s);
-                    V3 n2 = {f.nrm.x * sq, f.nrm.y * sq, f.nrm.z * sq};
-                    n1.x += -n2.x; n1.y += -n2.y; n1.z += -n2.z;
-                    src.x = f.hit.x + n1.x * 0.01; src.y = f.hit.y + n1.y * 0.01; src.z = f.hit.z + n1.z * 0.01;
-                    ray = n1;
-                    normalize(ray);
-                    exclude = -1; node = node * 2; depth++; descend = true;
-                }
-            } else if (f.stage == 1) {
-                f.stage = 2;
-                if (sv.f(G_SPECULAR, obj) > 0) {       // reflect whatever `ray` now holds, src/Raytrace.cpp:73-82
-                    V3 n1 = f.nrm;
-                    double k = n1.x * ray.x + n1.y * ray.y + n1.z * ray.z;
-                    n1.x *= k; n1.y *= k; n1.z *= k;
-                    n1.x *= 2; n1.y *= 2; n1.z *= 2;
-                    src = f.hit;
-                    ray.x = ray.x - n1.x; ray.y = ray.y - n1.y; ray.z = ray.z - n1.z;
-                    normalize(ray);
-                    exclude = obj; node = node * 2 + 1; depth++; descend = true;
-                }
-            } else {
-                uint32_t slot = 0xFFFFFFFFu;
-                if (sv.f(G_ABSORB, obj) > 0) {          // absorb branch is evaluated later, from the queue
-                    slot = atomicAdd(&ctr->n_sp, 1u);
-                    sp_store(q, slot, f.hit, f.nrm, obj, pixel, node | NODE_COMPLEX, c * 16 + node);
-                }
-                my[node].a = 2u | ((uint32_t)obj << 8);
-                my[node].b = slot;
-                depth--; node >>= 1;
+        struct Frame { V3 hit, nrm; int obj; int stage; };
+        Frame fr[4];
+        V3 src = fp.cam;
+        V3 ray = primary_ray(fp.width, fp.height, fp.cam, fp.K, pixel, x, y);
+        int depth = 0, exclude = -1;
+        uint32_t node = 1;
+        for (;;) {
+            // ---- enter traceRay(src, ray, exclude, bounce = depth) : src/Raytrace.cpp:32-47
+            bool returned = false;
+            if (depth > 3) returned = true;   // bounce > MAX_BOUNCES: opaque black, no draw, no table entry
+            else {
+                double dt = draw(item_key(fp.K, (uint64_t)pixel * 32u + node), 0);
+                if (depth > 0) nsec++;
+                V3 res = {0, 0, 0}, nrm = {0, 0, 0};
+                int obj = scene_intersect<MODE>(sv, src, ray, exclude, dt, res, nrm);
+                if (obj < 0) { my[node].a = 1; my[node].b = 0xFF000000u; returned = true; }
+                else if (is_light_patch(res)) { my[node].a = 1; my[node].b = light_colour(fp.light); returned = true; }
+                else { fr[depth].hit = res; fr[depth].nrm = nrm; fr[depth].obj = obj; fr[depth].stage = 0; }
             }
+            if (returned) { depth--; node >>= 1; }
+            // ---- resume frames until one of them makes a recursive call
+            bool descend = false;
+            while (depth >= 0 && !descend) {
+                Frame &f = fr[depth];
+                int obj = f.obj;
+                if (f.stage == 0) {
+                    f.stage = 1;
+                    if (sv.f(G_TRANSMISSION, obj) > 0) {   // refract, src/Raytrace.cpp:52-71
+                        double n = 1 / sv.f(G_REFRACTION, obj);
+                        double d = f.nrm.x * ray.x + f.nrm.y * ray.y + f.nrm.z * ray.z;
+                        V3 n1 = {f.nrm.x * d, f.nrm.y * d, f.nrm.z * d};
+                        n1.x = ray.x - n1.x; n1.y = ray.y - n1.y; n1.z = ray.z - n1.z;
+                        n1.x *= n; n1.y *= n; n1.z *= n;
+                        double s = 1 - (n * n) * (1 - d * d);
+                        double sq = sqrt(s);
+                        V3 n2 = {f.nrm.x * sq, f.nrm.y * sq, f.nrm.z * sq};
+                        n1.x += -n2.x; n1.y += -n2.y; n1.z += -n2.z;
+                        src.x = f.hit.x + n1.x * 0.01; src.y = f.hit.y + n1.y * 0.01; src.z = f.hit.z + n1.z * 0.01;
+                        ray = n1;
+                        normalize(ray);
+                        exclude = -1; node = node * 2; depth++; descend = true;
+                    }
+                } else if (f.stage == 1) {
+                    f.stage = 2;
+                    if (sv.f(G_SPECULAR, obj) > 0) {       // reflect whatever `ray` now holds, src/Raytrace.cpp:73-82
+                        V3 n1 = f.nrm;
+                        double k = n1.x * ray.x + n1.y * ray.y + n1.z * ray.z;
+                        n1.x *= k; n1.y *= k; n1.z *= k;
+                        n1.x *= 2; n1.y *= 2; n1.z *= 2;
+                        src = f.hit;
+                        ray.x = ray.x - n1.x; ray.y = ray.y - n1.y; ray.z = ray.z - n1.z;
+                        normalize(ray);
+                        exclude = obj; node = node * 2 + 1; depth++; descend = true;
+                    }
+                } else {
+                    uint32_t slot = 0xFFFFFFFFu;
+                    if (sv.f(G_ABSORB, obj) > 0) {          // absorb branch is evaluated later, from the queue
+                        slot = atomicAdd(&ctr->n_sp, 1u);
+                        sp_store(q, slot, f.hit, f.nrm, obj, pixel, node | NODE_COMPLEX, c * 16 + node);
+                    }
+                    my[node].a = 2u | ((uint32_t)obj << 8);
+                    my[node].b = slot;
+                    depth--; node >>= 1;
+                }
+            }
+            if (depth < 0) break;
         }
-        if (depth < 0) break;
     }
     if (nsec) atomicAdd(&ctr->n_secondary, nsec);
 }
 
 // shadow loop + direct term, src/Raytrace.cpp:174-212
 template <int MODE>
-__global__ __launch_bounds__(256) void k_shadow(SceneView gs, FrameParams fp, SPQueue q, uint32_t n_sp) {
+__global__ __launch_bounds__(256) void k_shadow(SceneView gs, FrameParams fp, SPQueue q, const Counters *ctr) {
     extern __shared__ __align__(16) unsigned char smem[];
     SceneView sv = gs;
     if (MODE == SCENE_LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
-    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_sp) return;
-    V3 p = {q.geo[0 * (size_t)q.cap + s], q.geo[1 * (size_t)q.cap + s], q.geo[2 * (size_t)q.cap + s]};
-    V3 nrm = {q.geo[3 * (size_t)q.cap + s], q.geo[4 * (size_t)q.cap + s], q.geo[5 * (size_t)q.cap + s]};
-    int obj = q.obj[s];
-    uint64_t IK = item_key(fp.K, (uint64_t)q.pixel[s] * 32u + (q.node[s] & 31u));
-    int light_count = 0;
-    V3 shadow_ray = {0, 0, 0};
-    for (int i = 0; i < 25; i++) {
-        double x0 = draw(IK, 1 + 3 * i) * 2 - 1;
-        double z0 = draw(IK, 2 + 3 * i) * 2 + 3;
-        double y0 = 4.95;
-        shadow_ray.x = x0 - p.x; shadow_ray.y = y0 - p.y; shadow_ray.z = z0 - p.z;
-        double max_dist = shadow_ray.x * shadow_ray.x + shadow_ray.y * shadow_ray.y + shadow_ray.z * shadow_ray.z;
-        normalize(shadow_ray);
-        double dt = draw(IK, 3 + 3 * i);
-        if (shadow_blocked<MODE>(sv, p, shadow_ray, dt, obj, max_dist)) light_count++;
+    const uint32_t n_sp = sp_total(ctr, q.cap);
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_sp; s += gridDim.x * blockDim.x) {
+        V3 p = {q.geo[0 * (size_t)q.cap + s], q.geo[1 * (size_t)q.cap + s], q.geo[2 * (size_t)q.cap + s]};
+        V3 nrm = {q.geo[3 * (size_t)q.cap + s], q.geo[4 * (size_t)q.cap + s], q.geo[5 * (size_t)q.cap + s]};
+        int obj = q.obj[s];
+        uint64_t IK = item_key(fp.K, (uint64_t)q.pixel[s] * 32u + (q.node[s] & 31u));
+        int light_count = 0;
+        V3 shadow_ray = {0, 0, 0};
+        for (int i = 0; i < 25; i++) {
+            double x0 = draw(IK, 1 + 3 * i) * 2 - 1;
+            double z0 = draw(IK, 2 + 3 * i) * 2 + 3;
+            double y0 = 4.95;
+            shadow_ray.x = x0 - p.x; shadow_ray.y = y0 - p.y; shadow_ray.z = z0 - p.z;
+            double max_dist = shadow_ray.x * shadow_ray.x + shadow_ray.y * shadow_ray.y + shadow_ray.z * shadow_ray.z;
+            normalize(shadow_ray);
+            double dt = draw(IK, 3 + 3 * i);
+            if (shadow_blocked<MODE>(sv, p, shadow_ray, dt, obj, max_dist)) light_count++;
+        }
+        double direct = 0;
+        if (light_count < 25) {
+            double d = nrm.x * shadow_ray.x + nrm.y * shadow_ray.y + nrm.z * shadow_ray.z;
+            if (d > 0) direct += d * 0.2 * (1 - (light_count / (double)25));
+            // the Blinn term at src/Raytrace.cpp:215-227 only feeds a variable that is never read
+        }
+        if (fp.flags & 4) direct = 0;
+        q.direct[s] = direct;
     }
-    double direct = 0;
-    if (light_count < 25) {
-        double d = nrm.x * shadow_ray.x + nrm.y * shadow_ray.y + nrm.z * shadow_ray.z;
-        if (d > 0) direct += d * 0.2 * (1 - (light_count / (double)25));
-        // the Blinn term at src/Raytrace.cpp:215-227 only feeds a variable that is never read
-    }
-    if (fp.flags & 4) direct = 0;
-    q.direct[s] = direct;
 }
 
 // ---- spatial order for the shade points of bounced pixels.  They come out of k_secondary in pixel order of the bounce
@@ -275,8 +300,9 @@ __global__ __launch_bounds__(256) void k_shadow(SceneView gs, FrameParams fp, SP
 // ones are neighbours on some surface and are gathered as a group like the shade points of a pixel tile.
 __device__ inline uint32_t sp_f2ord(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ inline float sp_ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
-__global__ __launch_bounds__(256) void k_sp_bounds(SPQueue q, uint32_t lo, uint32_t n, uint32_t *bounds) {
+__global__ __launch_bounds__(256) void k_sp_bounds(SPQueue q, const Counters *ctr, uint32_t *bounds) {
     __shared__ uint32_t part[4][6];
+    const uint32_t lo = ctr->n_sp0, n = ctr->n_bounced;
     uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0, 0, 0};
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         for (int a = 0; a < 3; a++) {
@@ -294,7 +320,8 @@ __global__ __launch_bounds__(256) void k_sp_bounds(SPQueue q, uint32_t lo, uint3
         if (threadIdx.x < 3) atomicMin(&bounds[threadIdx.x], v); else atomicMax(&bounds[threadIdx.x], v);
     }
 }
-__global__ __launch_bounds__(256) void k_sp_morton(SPQueue q, uint32_t lo, uint32_t n, const uint32_t *bounds, uint64_t *keys, uint32_t *vals) {
+__global__ __launch_bounds__(256) void k_sp_morton(SPQueue q, const Counters *ctr, const uint32_t *bounds, uint64_t *keys, uint32_t *vals) {
+    const uint32_t lo = ctr->n_sp0, n = ctr->n_bounced;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float ext = 0.f;
@@ -311,7 +338,8 @@ __global__ __launch_bounds__(256) void k_sp_morton(SPQueue q, uint32_t lo, uint3
 // candidate set is likely to pay: enough points, and an expected set size (the group kernel's own estimate, with the mean
 // photon density in place of a centre query) within `est_max`.  The others go to the `early` list: the per-query kernel
 // takes them on a stream of its own right away, beside the group kernels, instead of after them.
-__global__ __launch_bounds__(256) void k_sp_pieces(const uint64_t *keys, uint32_t n, double cell_rel, uint2 *pieces, Counters *ctr) {
+__global__ __launch_bounds__(256) void k_sp_pieces(const uint64_t *keys, double cell_rel, uint2 *pieces, Counters *ctr) {
+    const uint32_t n = ctr->n_bounced;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int level = 1;
@@ -327,27 +355,28 @@ __global__ __launch_bounds__(256) void k_sp_pieces(const uint64_t *keys, uint32_
 }
 __global__ __launch_bounds__(256) void k_sp_classify(SPQueue q, const uint32_t *sorted, const uint2 *pieces, const uint32_t *bounds, double photons_per_ext2,
                                                       double est_max, uint32_t min_run, uint2 *sgroups, Counters *ctr, uint32_t *early) {
-    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
-    if (w >= ctr->n_pieces) return;
-    const uint2 pc = pieces[w];
-    const uint32_t s = sorted[pc.x + min((uint32_t)lane, pc.y - 1u)];      // idle lanes repeat the last point
-    bool grouped = pc.y >= min_run;
-    if (grouped) {
-        float ext = 0.f;
-        for (int a = 0; a < 3; a++) ext = fmaxf(ext, sp_ord2f(bounds[3 + a]) - sp_ord2f(bounds[a]));
-        const double rho = photons_per_ext2 / fmax((double)ext * (double)ext, 1e-300);   // photons per unit of surface
-        const double rad = sqrt(PM_TILE_BETA2 * 63.0 / (3.14159265 * rho));
-        double e[3];
-        for (int a = 0; a < 3; a++) { double v = q.geo[a * (size_t)q.cap + s]; e[a] = wave_max_f64(v) - wave_min_f64(v) + 2 * rad; }
-        grouped = e[0] * e[1] * e[2] / fmin(e[0], fmin(e[1], e[2])) * rho <= est_max;
-    }
-    if (grouped) { if (lane == 0) sgroups[atomicAdd(&ctr->n_sgroups, 1u)] = pc; }
-    else {
-        uint32_t b0 = 0;
-        if (lane == 0) b0 = atomicAdd(&ctr->n_early, pc.y);
-        b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
-        if ((uint32_t)lane < pc.y) early[b0 + (uint32_t)lane] = s;
+    const uint32_t n_pieces = ctr->n_pieces, waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n_pieces; w += waves) {
+        const uint2 pc = pieces[w];
+        const uint32_t s = sorted[pc.x + min((uint32_t)lane, pc.y - 1u)];      // idle lanes repeat the last point
+        bool grouped = pc.y >= min_run;
+        if (grouped) {
+            float ext = 0.f;
+            for (int a = 0; a < 3; a++) ext = fmaxf(ext, sp_ord2f(bounds[3 + a]) - sp_ord2f(bounds[a]));
+            const double rho = photons_per_ext2 / fmax((double)ext * (double)ext, 1e-300);   // photons per unit of surface
+            const double rad = sqrt(PM_TILE_BETA2 * 63.0 / (3.14159265 * rho));
+            double e[3];
+            for (int a = 0; a < 3; a++) { double v = q.geo[a * (size_t)q.cap + s]; e[a] = wave_max_f64(v) - wave_min_f64(v) + 2 * rad; }
+            grouped = e[0] * e[1] * e[2] / fmin(e[0], fmin(e[1], e[2])) * rho <= est_max;
+        }
+        if (grouped) { if (lane == 0) sgroups[atomicAdd(&ctr->n_sgroups, 1u)] = pc; }
+        else {
+            uint32_t b0 = 0;
+            if (lane == 0) b0 = atomicAdd(&ctr->n_early, pc.y);
+            b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+            if ((uint32_t)lane < pc.y) early[b0 + (uint32_t)lane] = s;
+        }
     }
 }
 
@@ -356,41 +385,45 @@ __global__ __launch_bounds__(256) void k_sp_classify(SPQueue q, const uint32_t *
 // map builds beside it (default scene: the pass itself 0.24 -> 0.28 ms, the step 3.10 -> 3.05 ms; 10 000 spheres, where a
 // ray ends at its first blocker or walks cells all the way to the light: step 13.3 -> 11.8 ms).
 template <int MODE>
-__global__ __launch_bounds__(256) void k_shadow_rays(SceneView gs, FrameParams fp, SPQueue q, uint32_t n_sp) {
+__global__ __launch_bounds__(256) void k_shadow_rays(SceneView gs, FrameParams fp, SPQueue q, const Counters *ctr) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int blocked[10];
     SceneView sv = gs;
     if (MODE == SCENE_LDS) { sv = stage_scene(gs, smem); }
-    if (threadIdx.x < 10) blocked[threadIdx.x] = 0;
-    __syncthreads();
+    const uint32_t n_sp = sp_total(ctr, q.cap);      // launched for the queue's capacity: blocks take groups of 10 shade points in turn
     const uint32_t local = threadIdx.x / 25u, i = threadIdx.x % 25u;
-    const uint32_t s = blockIdx.x * 10u + local;
-    const bool live = threadIdx.x < 250u && s < n_sp;
-    V3 p = {0, 0, 0}, nrm = {0, 0, 0}, shadow_ray = {0, 0, 0};
-    if (live) {
-        p = {q.geo[0 * (size_t)q.cap + s], q.geo[1 * (size_t)q.cap + s], q.geo[2 * (size_t)q.cap + s]};
-        const int obj = q.obj[s];
-        const uint64_t IK = item_key(fp.K, (uint64_t)q.pixel[s] * 32u + (q.node[s] & 31u));
-        const double x0 = draw(IK, 1 + 3 * i) * 2 - 1;
-        const double z0 = draw(IK, 2 + 3 * i) * 2 + 3;
-        const double y0 = 4.95;
-        shadow_ray.x = x0 - p.x; shadow_ray.y = y0 - p.y; shadow_ray.z = z0 - p.z;
-        const double max_dist = shadow_ray.x * shadow_ray.x + shadow_ray.y * shadow_ray.y + shadow_ray.z * shadow_ray.z;
-        normalize(shadow_ray);
-        const double dt = draw(IK, 3 + 3 * i);
-        if (shadow_blocked<MODE>(sv, p, shadow_ray, dt, obj, max_dist)) atomicAdd(&blocked[local], 1);
-    }
-    __syncthreads();
-    if (live && i == 24u) {        // the direct term uses the direction of the LAST shadow ray, src/Raytrace.cpp:207-212
-        nrm = {q.geo[3 * (size_t)q.cap + s], q.geo[4 * (size_t)q.cap + s], q.geo[5 * (size_t)q.cap + s]};
-        const int light_count = blocked[local];
-        double direct = 0;
-        if (light_count < 25) {
-            double d = nrm.x * shadow_ray.x + nrm.y * shadow_ray.y + nrm.z * shadow_ray.z;
-            if (d > 0) direct += d * 0.2 * (1 - (light_count / (double)25));
+    for (uint32_t g = blockIdx.x; g * 10u < n_sp; g += gridDim.x) {
+        if (threadIdx.x < 10) blocked[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t s = g * 10u + local;
+        const bool live = threadIdx.x < 250u && s < n_sp;
+        V3 p = {0, 0, 0}, nrm = {0, 0, 0}, shadow_ray = {0, 0, 0};
+        if (live) {
+            p = {q.geo[0 * (size_t)q.cap + s], q.geo[1 * (size_t)q.cap + s], q.geo[2 * (size_t)q.cap + s]};
+            const int obj = q.obj[s];
+            const uint64_t IK = item_key(fp.K, (uint64_t)q.pixel[s] * 32u + (q.node[s] & 31u));
+            const double x0 = draw(IK, 1 + 3 * i) * 2 - 1;
+            const double z0 = draw(IK, 2 + 3 * i) * 2 + 3;
+            const double y0 = 4.95;
+            shadow_ray.x = x0 - p.x; shadow_ray.y = y0 - p.y; shadow_ray.z = z0 - p.z;
+            const double max_dist = shadow_ray.x * shadow_ray.x + shadow_ray.y * shadow_ray.y + shadow_ray.z * shadow_ray.z;
+            normalize(shadow_ray);
+            const double dt = draw(IK, 3 + 3 * i);
+            if (shadow_blocked<MODE>(sv, p, shadow_ray, dt, obj, max_dist)) atomicAdd(&blocked[local], 1);
         }
-        if (fp.flags & 4) direct = 0;
-        q.direct[s] = direct;
+        __syncthreads();
+        if (live && i == 24u) {        // the direct term uses the direction of the LAST shadow ray, src/Raytrace.cpp:207-212
+            nrm = {q.geo[3 * (size_t)q.cap + s], q.geo[4 * (size_t)q.cap + s], q.geo[5 * (size_t)q.cap + s]};
+            const int light_count = blocked[local];
+            double direct = 0;
+            if (light_count < 25) {
+                double d = nrm.x * shadow_ray.x + nrm.y * shadow_ray.y + nrm.z * shadow_ray.z;
+                if (d > 0) direct += d * 0.2 * (1 - (light_count / (double)25));
+            }
+            if (fp.flags & 4) direct = 0;
+            q.direct[s] = direct;
+        }
+        __syncthreads();               // `blocked` is cleared for the next group
     }
 }
 
@@ -434,8 +467,9 @@ struct WorkDraw {
 
 // One wave per shade point (pm_grid.h).  Items are the shade points the group kernel left: `left[0 .. *n_left)`, then the
 // slots [sec_lo, sec_lo + sec_n) of the bounced pixels' shade points, which come in no spatial order at all.
+// sec_mode: which slots follow the list: 0 none, 1 the bounced pixels' shade points [n_sp0, n_sp0 + n_bounced), 2 every shade point
 template <int KIND>
-__global__ __launch_bounds__(256) void k_gather(MapView m_in, SPQueue q, const uint32_t *left, const uint32_t *n_left, uint32_t sec_lo, uint32_t sec_n,
+__global__ __launch_bounds__(256) void k_gather(MapView m_in, SPQueue q, const uint32_t *left, const uint32_t *n_left, const Counters *ctr, int sec_mode,
                                                 uint32_t *sched) {
     MapView m = m_in;
     load_grid(m);
@@ -444,6 +478,8 @@ __global__ __launch_bounds__(256) void k_gather(MapView m_in, SPQueue q, const u
     KnnBuf *buf = &bufs[wave_in_block];
     int lane = threadIdx.x & 63;
     double *out = KIND == 0 ? q.rad_g : q.rad_c;
+    const uint32_t sec_lo = sec_mode == 1 ? ctr->n_sp0 : 0u;
+    const uint32_t sec_n = sec_mode == 1 ? ctr->n_bounced : (sec_mode == 2 ? sp_total(ctr, q.cap) : 0u);
     const uint32_t nl = *n_left, n_items = nl + sec_n;
     WorkDraw wd;
 #ifdef PM_WAVE_TIMES
@@ -499,7 +535,8 @@ __global__ __launch_bounds__(64) void k_gather_tile(MapView m_in, SPQueue q, con
         uint32_t s;
         if (i0 < n_tiles) {
             const uint2 g = groups[i0];
-            active = (uint32_t)lane < g.y;
+            if (g.x >= q.cap) continue;                       // a queue that overflowed (the frame is rendered again): nothing of it is touched
+            active = (uint32_t)lane < g.y && g.x + (uint32_t)lane < q.cap;
             s = g.x + (active ? (uint32_t)lane : 0u);
         } else {
             const uint2 g = sgroups[i0 - n_tiles];
@@ -598,13 +635,7 @@ __global__ __launch_bounds__(256) void k_knn_query(MapView m_in, const double *p
 }
 
 // clamp / colour / pack, src/Raytrace.cpp:230-242 ; simple pixels also get their final mix (:245-257)
-template <int MODE>
-__global__ __launch_bounds__(256) void k_shade(SceneView gs, FrameParams fp, SPQueue q, uint32_t n_sp, uint32_t *pane, NodeEntry *tab) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    SceneView sv = gs;
-    if (MODE == SCENE_LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
-    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_sp) return;
+__device__ inline void shade_point(const SceneView &sv, const FrameParams &fp, const SPQueue &q, uint32_t s, uint32_t *pane, NodeEntry *tab) {
     int obj = q.obj[s];
     double direct = q.direct[s];
     double gr = 0, gg = 0, gb = 0, cr = 0, cg = 0, cb = 0;
@@ -622,15 +653,17 @@ __global__ __launch_bounds__(256) void k_shade(SceneView gs, FrameParams fp, SPQ
     if (node & NODE_COMPLEX) tab[q.tabslot[s]].b = absorb_res;   // slot -> colour, consumed by k_resolve
     else pane[q.pixel[s]] = mix_colour(0, 0, absorb_res, sv.f(G_SPECULAR, obj), sv.f(G_TRANSMISSION, obj), sv.f(G_ABSORB, obj));
 }
-
 template <int MODE>
-__global__ __launch_bounds__(256) void k_resolve(SceneView gs, const uint32_t *complex_list, uint32_t n_complex, const NodeEntry *tab, uint32_t *pane) {
+__global__ __launch_bounds__(256) void k_shade(SceneView gs, FrameParams fp, SPQueue q, const Counters *ctr, uint32_t *pane, NodeEntry *tab) {
     extern __shared__ __align__(16) unsigned char smem[];
     SceneView sv = gs;
     if (MODE == SCENE_LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
-    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_complex) return;
-    const NodeEntry *my = tab + (size_t)c * 16;
+    const uint32_t n_sp = sp_total(ctr, q.cap);
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_sp; s += gridDim.x * blockDim.x) shade_point(sv, fp, q, s, pane, tab);
+}
+
+// folds the node table of one bounced pixel bottom-up into its final colour (the mixes of traceRay's returns, src/Raytrace.cpp:245-257)
+__device__ inline uint32_t resolve_pixel(const SceneView &sv, const NodeEntry *my) {
     uint32_t col[32];
 #pragma unroll
     for (int i = 0; i < 32; i++) col[i] = 0;   // a branch that was not taken contributes 0 (refract_res / reflect_res initial value)
@@ -650,7 +683,16 @@ __global__ __launch_bounds__(256) void k_resolve(SceneView gs, const uint32_t *c
         }
         col[node] = v;
     }
-    pane[complex_list[c]] = col[1];
+    return col[1];
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k_resolve(SceneView gs, const uint32_t *complex_list, const Counters *ctr, uint32_t c_cap, const NodeEntry *tab, uint32_t *pane) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    SceneView sv = gs;
+    if (MODE == SCENE_LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
+    const uint32_t n_complex = min(ctr->n_complex, c_cap);
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n_complex; c += gridDim.x * blockDim.x)
+        pane[complex_list[c]] = resolve_pixel(sv, tab + (size_t)c * 16);
 }
 
 }  // namespace pm

@@ -55,6 +55,7 @@ struct KnnBuf {
     uint32_t i[KBUF];            // photon index in sorted order
     unsigned long long acc[4];   // fixed-point radiance accumulators (3 used)
     uint32_t hist[64];           // d2 histogram of the select
+    unsigned long long sel[64];  // the entries of the histogram bin in which the count crosses 63
     uint32_t cellpre[128];       // scan list of the grid query (pm_grid.h)
 };
 
@@ -175,46 +176,67 @@ __device__ __noinline__ unsigned long long knn_reduce_impl(KnnBuf *buf_in, int c
         act[s] = __ballot(lane + 64 * s < count && bin[s] == (uint32_t)bstar);
         remaining += __popcll(act[s]);
     }
-    // Stage 2: exact select of the need-th smallest among the entries of that bin: binary radix select on the
-    // IEEE bit patterns (ballots + scalar popcounts), common leading bits skipped.
-    uint32_t o_hi = 0, o_lo = 0, a_hi = 0xFFFFFFFFu, a_lo = 0xFFFFFFFFu;
-    unsigned long long diff = 0ULL;
-    if (remaining > 1) {
+    // Stage 2: exact select of the need-th smallest among the entries of that bin.  The bin holds a handful of entries
+    // (a 64th of the buffer when the distances are spread evenly): they are gathered into LDS, every lane takes one and
+    // counts how many are smaller and how many are not larger -- one broadcast read and two compares per entry -- and
+    // the entry whose rank interval holds `need` is the answer.  (A bin of more than 64 entries -- hundreds of equal
+    // distances -- falls back to a binary radix select on the IEEE bit patterns: ballots + scalar popcounts.)
+    unsigned long long tau = 0ULL;
+    if (remaining <= 64) {
+        int run = 0;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            if (act[s] == 0ULL) continue;
+            if ((act[s] >> lane) & 1ULL) buf->sel[run + lane_rank(act[s])] = v[s];
+            run += __popcll(act[s]);
+        }
+        wave_lds_fence();
+        const unsigned long long x = lane < remaining ? buf->sel[lane] : ~0ULL;
+        int less = 0, leq = 0;
+        for (int k = 0; k < remaining; k++) {
+            const unsigned long long y = buf->sel[k];
+            less += y < x ? 1 : 0;
+            leq += y <= x ? 1 : 0;
+        }
+        const unsigned long long hitm = __ballot(lane < remaining && less < need && need <= leq);   // every such lane holds the same value
+        tau = readlane_u64(x, __ffsll((long long)hitm) - 1);
+    } else {
+        uint32_t o_hi = 0, o_lo = 0, a_hi = 0xFFFFFFFFu, a_lo = 0xFFFFFFFFu;
+        unsigned long long diff = 0ULL;
 #pragma unroll
         for (int s = 0; s < NS; s++)
             if ((act[s] >> lane) & 1ULL) { o_hi |= (uint32_t)(v[s] >> 32); o_lo |= (uint32_t)v[s]; a_hi &= (uint32_t)(v[s] >> 32); a_lo &= (uint32_t)v[s]; }
         diff = (((unsigned long long)(wave_or_u32(o_hi) ^ wave_and_u32(a_hi))) << 32) | (wave_or_u32(o_lo) ^ wave_and_u32(a_lo));
-    }
-    if (diff != 0ULL) {
-        for (int b = 63 - __clzll((long long)diff); b >= 0 && remaining > 1; b--) {
-            uint32_t bit = 1u << (b & 31);
-            unsigned long long z[NS];
-            int zero_cnt = 0;
+        if (diff != 0ULL) {
+            for (int b = 63 - __clzll((long long)diff); b >= 0 && remaining > 1; b--) {
+                uint32_t bit = 1u << (b & 31);
+                unsigned long long z[NS];
+                int zero_cnt = 0;
 #pragma unroll
-            for (int s = 0; s < NS; s++) {
-                z[s] = 0ULL;
-                if (act[s] == 0ULL) continue;
-                uint32_t w = b >= 32 ? (uint32_t)(v[s] >> 32) : (uint32_t)v[s];
-                z[s] = __ballot((w & bit) == 0u) & act[s];
-                zero_cnt += __popcll(z[s]);
-            }
-            if (need <= zero_cnt) {
+                for (int s = 0; s < NS; s++) {
+                    z[s] = 0ULL;
+                    if (act[s] == 0ULL) continue;
+                    uint32_t w = b >= 32 ? (uint32_t)(v[s] >> 32) : (uint32_t)v[s];
+                    z[s] = __ballot((w & bit) == 0u) & act[s];
+                    zero_cnt += __popcll(z[s]);
+                }
+                if (need <= zero_cnt) {
 #pragma unroll
-                for (int s = 0; s < NS; s++) act[s] = z[s];
-                remaining = zero_cnt;
-            } else {
-                need -= zero_cnt;
+                    for (int s = 0; s < NS; s++) act[s] = z[s];
+                    remaining = zero_cnt;
+                } else {
+                    need -= zero_cnt;
 #pragma unroll
-                for (int s = 0; s < NS; s++) act[s] &= ~z[s];
-                remaining -= zero_cnt;
+                    for (int s = 0; s < NS; s++) act[s] &= ~z[s];
+                    remaining -= zero_cnt;
+                }
             }
         }
-    }
-    // every still-active entry equals the answer
-    unsigned long long tau = 0ULL;
+        // every still-active entry equals the answer
 #pragma unroll
-    for (int s = NS - 1; s >= 0; s--)
-        if (act[s]) tau = readlane_u64(v[s], __ffsll((long long)act[s]) - 1);
+        for (int s = NS - 1; s >= 0; s--)
+            if (act[s]) tau = readlane_u64(v[s], __ffsll((long long)act[s]) - 1);
+    }
     // compact: all entries < tau, then enough entries == tau to make 63
     unsigned long long lt[NS], eq[NS];
     int n_lt = 0;

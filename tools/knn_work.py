@@ -14,7 +14,10 @@ sel = np.flatnonzero((flat >= 0) & (flat <= 4))[::8] if only == 'walls' else np.
 for kind in (0, 1):
     m = ctx.create_map(kind, n, 12345)
     t = time.time(); found, idx, d2, work = ctx.knn_profile(m, pts[sel]); dt = time.time() - t
+    fast = (work[:, 0] & 0x80000000) != 0          # the block query answered (no walk)
+    work = work.copy(); work[:, 0] &= 0x7FFFFFFF
     w = work.astype(np.float64)
+    print(f"   block query answered {fast.mean() * 100:.1f}% of the queries")
     print(f"kind {kind} n={n} queries={len(sel)} wall={dt*1e3:.1f}ms  mean nodes={w[:,0].mean():.1f} leaves={w[:,1].mean():.1f} reduces={w[:,2].mean():.2f} cands={w[:,3].mean():.1f}")
     for p in (50, 90, 99, 100):
         print(f"   p{p}: nodes={np.percentile(w[:,0],p):.0f} leaves={np.percentile(w[:,1],p):.0f} reduces={np.percentile(w[:,2],p):.0f} cands={np.percentile(w[:,3],p):.0f}")
