@@ -191,6 +191,7 @@ def main():
     phase = {k: 0.0 for k in ("ms_primary", "ms_secondary", "ms_shadow", "ms_gather_global", "ms_gather_caustic", "ms_gather", "ms_group_global",
                               "ms_group_caustic", "ms_resolve", "ms_total")}
     t_maps = 0.0
+    map_ms = [[0.0, 0.0], [0.0, 0.0]]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ta = time.perf_counter()
@@ -200,6 +201,10 @@ def main():
         frame.gather_pane()
         for k in phase:
             phase[k] += getattr(st, k)
+        for kind, m in enumerate(frame.maps):      # device times of the two phases of each map's build (HIP events on its build stream)
+            if m is not None:
+                te, tb = m.times()
+                map_ms[kind][0] += te; map_ms[kind][1] += tb
     sync()
     dt = time.perf_counter() - t0
 
@@ -236,7 +241,9 @@ def main():
                                                                                    "every map emitted on every rank, no exchange" if maps_mode == "replicate" else "one rank"),
                        "maps_autotune_ms_per_step": maps_tune},
             "gathers_per_s": gathers / step_s, "frame_time_s": step_s, "rays_per_frame": rays, "gathers_per_frame": gathers,
-            "phases_ms_rank0": {**{k: v / args.steps for k, v in phase.items()}, "maps_enqueue_host_wall": t_maps / args.steps * 1e3},
+            "phases_ms_rank0": {**{k: v / args.steps for k, v in phase.items()}, "maps_enqueue_host_wall": t_maps / args.steps * 1e3,
+                                "map_global_emit": map_ms[0][0] / args.steps, "map_global_index": map_ms[0][1] / args.steps,
+                                "map_caustic_emit": map_ms[1][0] / args.steps, "map_caustic_index": map_ms[1][1] / args.steps},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "note": f"algorithmic bytes = {ALGO_BYTES_PER_GATHER} B x {int(dom_units)} gathers answered per launch; avg launch {dom_ms:.3f} ms "

@@ -60,6 +60,7 @@ static __device__ __align__(256) unsigned char scratch[ES_BYTES];
 
 constexpr size_t LDS_SCENE_MAX = 48 * 1024;   // scenes up to this size are staged in LDS; larger ones are read from global memory
 constexpr int N_EVENTS = 8;
+constexpr int N_SCHED = 20;        // gather launches of a frame, at most: per map 4 group parts + 4 per-query launches behind them + 1 beside them
 
 struct BuildSlot {
     hipStream_t stream = nullptr;
@@ -79,6 +80,8 @@ struct pm_ctx {
     hipEvent_t ev_join2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_g[2][3] = {};          // per map: gather begins, group kernel done, per-query kernel done
+    hipEvent_t ev_part[2][4] = {};       // per map: a part of the group launches is done (its leftovers may be gathered)
+    int tile_parts = 1;                  // launches the groups of a map are cut into (PM_TILE_PARTS, 1..4; measured: more than one is slower)
     // scene
     int nprims = 0, stride = 0;
     double yield[2] = {0.60, 0.36};   // stored photons per emission attempt (global, caustic): the reference scene's to begin with, then
@@ -146,6 +149,7 @@ static int ctx_init(pm_ctx *ctx) {
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     for (int k = 0; k < 2; k++) for (int i = 0; i < 3; i++) HIPCHK(hipEventCreate(&ctx->ev_g[k][i]));
+    for (int k = 0; k < 2; k++) for (int i = 0; i < 4; i++) HIPCHK(hipEventCreateWithFlags(&ctx->ev_part[k][i], hipEventDisableTiming));
     // this GPU's copy of the static scratch array (the device is current: pm_ctx_create set it)
     HIPCHK(hipGetSymbolAddress((void **)&ctx->static_scratch, HIP_SYMBOL(scratch)));
     if (!ctx->static_scratch) return fail(PM_EHIP, "hipGetSymbolAddress(scratch) returned NULL");
@@ -191,6 +195,7 @@ extern "C" int pm_ctx_destroy(pm_ctx *ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     for (int k = 0; k < 2; k++) for (int i = 0; i < 3; i++) if (ctx->ev_g[k][i]) (void)hipEventDestroy(ctx->ev_g[k][i]);
+    for (int k = 0; k < 2; k++) for (int i = 0; i < 4; i++) if (ctx->ev_part[k][i]) (void)hipEventDestroy(ctx->ev_part[k][i]);
     delete ctx;
     return PM_OK;
 }
@@ -404,12 +409,12 @@ static int slot_scratch(BuildSlot &sl, uint64_t count, EmitScratch &es) {
 constexpr uint64_t EMIT_CHUNK = 1ULL << 24;   // attempts per launch of a map's emission (512 MB of attempt records per build slot)
 // d_running != NULL: this range appends behind the ranges emitted before it (k_scan_blocks); *h_got then receives the total so far
 static int emit_range_on(pm_ctx *ctx, hipStream_t stream, const EmitScratch &es, int kind, uint64_t seed, const double lc[3], uint64_t a0, uint64_t count,
-                         pm_photon *d_out, uint64_t cap, uint64_t *h_got, uint64_t *total, uint64_t *d_running = nullptr) {
+                         pm_photon *d_out, uint64_t cap, uint64_t *h_got, uint64_t *total, uint64_t *d_running = nullptr, uint32_t *bounds_init = nullptr) {
     uint32_t nb = (uint32_t)((count + 255) / 256);
     uint64_t K = stream_key(seed, kind == PM_MAP_GLOBAL ? KIND_EMIT_GLOBAL : KIND_EMIT_CAUSTIC);
     V3 light = {lc[0], lc[1], lc[2]};
     LAUNCH_SCENE_ON(k_emit, dim3(nb), dim3(256), ctx, stream, kind, K, light, a0, count, es.tmp, es.flag, es.counts);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, es.counts, es.offs, nb, d_running);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, es.counts, es.offs, nb, d_running, bounds_init);
     hipLaunchKernelGGL(k_emit_scatter, dim3(nb), dim3(256), 0, stream, es.tmp, es.flag, es.offs, count, d_out, cap);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h_got, es.offs + nb, 8, hipMemcpyDeviceToHost, stream));
@@ -419,12 +424,12 @@ static int emit_range_on(pm_ctx *ctx, hipStream_t stream, const EmitScratch &es,
     return PM_OK;
 }
 static int emit_range(pm_ctx *ctx, BuildSlot &sl, int kind, uint64_t seed, const double lc[3], uint64_t a0, uint64_t count, pm_photon *d_out,
-                      uint64_t cap, uint64_t *h_got, uint64_t *total, uint64_t *d_running = nullptr) {
+                      uint64_t cap, uint64_t *h_got, uint64_t *total, uint64_t *d_running = nullptr, uint32_t *bounds_init = nullptr) {
     if (count == 0) { *h_got = 0; if (total) *total = 0; return PM_OK; }
     if (count > (1ULL << 31)) return fail(PM_EINVAL, "emit_range: at most 2^31 attempts per call");
     EmitScratch es;
     PMCHK(slot_scratch(sl, count, es));
-    return emit_range_on(ctx, sl.stream, es, kind, seed, lc, a0, count, d_out, cap, h_got, total, d_running);
+    return emit_range_on(ctx, sl.stream, es, kind, seed, lc, a0, count, d_out, cap, h_got, total, d_running, bounds_init);
 }
 
 extern "C" int pm_emit_range(pm_ctx *ctx, int32_t map_kind, uint64_t seed, const double light_color[3], uint64_t attempt_begin,
@@ -477,7 +482,7 @@ extern "C" int pm_emit_shard(pm_ctx *ctx, int32_t map_kind, uint64_t seed, const
 }
 
 // ---------------------------------------------------------------------------------------- build
-static int build_index(pm_map *map, BuildSlot &sl) {
+static int build_index(pm_map *map, BuildSlot &sl, bool bounds_reset = false) {
     long long n = map->n;
     MapView &v = map->view;
     memset(&v, 0, sizeof(v));
@@ -489,37 +494,42 @@ static int build_index(pm_map *map, BuildSlot &sl) {
     PMCHK(sl.vals_in.ensure((size_t)n * 4)); PMCHK(sl.vals_out.ensure((size_t)n * 4));
     PMCHK(sl.bounds.ensure(6 * 4));
     PMCHK(map->pos4.ensure((size_t)n * 16)); PMCHK(map->rest.ensure((size_t)n * 16));
-    uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
-    HIPCHK(hipMemcpyAsync(sl.bounds.p, init, sizeof(init), hipMemcpyHostToDevice, sl.stream));
+    // (the six bounds words were reset by the emission's scan kernel when this map was emitted here; otherwise now)
+    if (!bounds_reset) {
+        HIPCHK(hipMemsetAsync(sl.bounds.p, 0xFF, 12, sl.stream));
+        HIPCHK(hipMemsetAsync(sl.bounds.as<unsigned char>() + 12, 0, 12, sl.stream));
+    }
     unsigned nbk = (unsigned)std::min<long long>((n + 255) / 256, 512);
     unsigned nb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_bounds, dim3(nbk), dim3(256), 0, sl.stream, rec, n, sl.bounds.as<uint32_t>());
-    hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, sl.stream, rec, n, sl.bounds.as<uint32_t>(), sl.keys_in.as<uint64_t>(),
-                       sl.vals_in.as<uint32_t>());
-    // 30-bit radix sort (pm_sort.h) straight into the map's key array
+    const uint32_t sort_blocks = (uint32_t)((n + SORT_TILE - 1) / SORT_TILE);
     PMCHK(sl.sort_tmp.ensure(sort_scratch_words((uint32_t)n) * 4));
     PMCHK(map->keys.ensure((size_t)n * 8));
-    HIPCHK(radix_sort_pairs_30(sl.stream, sl.keys_in.as<uint64_t>(), sl.vals_in.as<uint32_t>(), map->keys.as<uint64_t>(), sl.vals_out.as<uint32_t>(),
-                               sl.sort_tmp.as<uint32_t>(), (uint32_t)n, nullptr));
-    hipLaunchKernelGGL(k_permute, dim3(nb), dim3(256), 0, sl.stream, rec, sl.vals_out.as<uint32_t>(), n, map->pos4.as<float4>(),
-                       map->rest.as<uint4>());
-    // linear octree tables
+    PMCHK(map->grid.ensure(sizeof(GridParams) + 16));
+    // linear octree: the finest table level holds about two cells per photon
     int lmax = 0;
     while (lmax < 8 && (1LL << (3 * (lmax + 1))) <= 4 * n) lmax++;
-    long long ncells = cell_off(lmax + 1);
-    PMCHK(map->cells.ensure((size_t)ncells * 4));
-    hipLaunchKernelGGL(k_cell_tables, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, sl.stream, map->keys.as<uint64_t>(), n,
-                       map->cells.as<uint32_t>(), lmax);
+    const long long n_entries = (1LL << (3 * lmax)) + 1;
+    const uint32_t fill_blocks = (uint32_t)((n_entries + FILL_TILE - 1) / FILL_TILE);
+    PMCHK(map->cells.ensure((size_t)n_entries * 4 + (size_t)fill_blocks * 4));
     PMCHK(map->cbox.ensure((size_t)box_off(lmax + 1) * 8));
-    hipLaunchKernelGGL(k_cell_boxes_fine, dim3((unsigned)(((1LL << (3 * lmax)) + 255) / 256)), dim3(256), 0, sl.stream, map->pos4.as<float4>(),
-                       map->cells.as<uint32_t>(), lmax, sl.bounds.as<uint32_t>(), map->cbox.as<uint64_t>());
-    int l = lmax - 1;
-    for (; l > 3; l--)
-        hipLaunchKernelGGL(k_cell_boxes_up, dim3((unsigned)(((1LL << (3 * l)) + 255) / 256)), dim3(256), 0, sl.stream, map->cells.as<uint32_t>(), l,
-                           map->cbox.as<uint64_t>());
-    if (l >= 0) hipLaunchKernelGGL(k_cell_boxes_top, dim3(1), dim3(256), 0, sl.stream, map->cells.as<uint32_t>(), l, map->cbox.as<uint64_t>());
-    PMCHK(map->grid.ensure(sizeof(GridParams)));
-    hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(64), 0, sl.stream, sl.bounds.as<uint32_t>(), map->grid.as<GridParams>());
+    uint32_t *cells = map->cells.as<uint32_t>(), *bmin = cells + n_entries;
+    hipLaunchKernelGGL(k_bounds, dim3(nbk), dim3(256), 0, sl.stream, rec, n, sl.bounds.as<uint32_t>());
+    // keys + the sort's first histogram + the grid numbers; 30-bit radix sort (pm_sort.h) straight into the map's key array
+    hipLaunchKernelGGL(k_morton, dim3(sort_blocks), dim3(256), 0, sl.stream, rec, n, sl.bounds.as<uint32_t>(), sl.keys_in.as<uint64_t>(), sl.vals_in.as<uint32_t>(),
+                       sort_blocks, sl.sort_tmp.as<uint32_t>(), map->grid.as<GridParams>());
+    HIPCHK(radix_sort_pairs_30(sl.stream, sl.keys_in.as<uint64_t>(), sl.vals_in.as<uint32_t>(), map->keys.as<uint64_t>(), sl.vals_out.as<uint32_t>(),
+                               sl.sort_tmp.as<uint32_t>(), (uint32_t)n, nullptr, true));
+    // the cell table: preset, first photons of the occupied cells (k_permute), empty cells filled from the right
+    HIPCHK(hipMemsetAsync(cells, 0xFF, (size_t)n_entries * 4, sl.stream));
+    hipLaunchKernelGGL(k_permute, dim3(nb), dim3(256), 0, sl.stream, rec, sl.vals_out.as<uint32_t>(), map->keys.as<uint64_t>(), n, lmax, map->pos4.as<float4>(),
+                       map->rest.as<uint4>(), cells);
+    hipLaunchKernelGGL(k_fill_mins, dim3(fill_blocks), dim3(256), 0, sl.stream, cells, n_entries, bmin);
+    hipLaunchKernelGGL(k_fill_cells, dim3(fill_blocks), dim3(256), 0, sl.stream, cells, n_entries, bmin, fill_blocks);
+    // cell boxes: the finest level and up to three levels above it per subtree, then the few levels on top
+    const int depth = std::min(3, lmax);
+    hipLaunchKernelGGL(k_cell_boxes_tree, dim3((unsigned)(1LL << (3 * (lmax - depth)))), dim3(256), 0, sl.stream, map->pos4.as<float4>(), cells, lmax, depth,
+                       sl.bounds.as<uint32_t>(), map->cbox.as<uint64_t>());
+    if (lmax - depth - 1 >= 0) hipLaunchKernelGGL(k_cell_boxes_top, dim3(1), dim3(256), 0, sl.stream, lmax - depth - 1, map->cbox.as<uint64_t>());
     v.grid = map->grid.as<GridParams>();   // (glo / gext / gu stay zero on the host: kernels load them from here)
     v.lmax = lmax; v.cells = map->cells.as<uint32_t>(); v.keys = map->keys.as<uint64_t>(); v.cbox = map->cbox.as<uint64_t>();
     v.pos4 = map->pos4.as<float4>(); v.rest = map->rest.as<uint4>();
@@ -680,16 +690,17 @@ extern "C" int pm_map_create(pm_ctx *ctx, int32_t map_kind, int64_t n, uint64_t 
         const uint64_t total = n > 0 ? std::min<uint64_t>((uint64_t)((double)n / yield) + 4096, 1ULL << 36) : 0;
         map->h_got[0] = 0;
         rc = stamp(map->t_begin, nullptr, sl.stream);
+        if (rc == PM_OK) rc = sl.bounds.ensure(6 * 4);
         if (total > EMIT_CHUNK) {
             rc = sl.emit_run.ensure(8);
             if (rc == PM_OK && hipMemsetAsync(sl.emit_run.p, 0, 8, sl.stream) != hipSuccess) rc = fail(PM_EHIP, "pm_map_create: hipMemsetAsync failed");
         }
         for (uint64_t a0 = 0; rc == PM_OK && a0 < total; a0 += EMIT_CHUNK)
             rc = emit_range(ctx, sl, map_kind, seed, light_color, a0, std::min<uint64_t>(EMIT_CHUNK, total - a0), map->records.as<pm_photon>(), (uint64_t)n, map->h_got, nullptr,
-                            total > EMIT_CHUNK ? sl.emit_run.as<uint64_t>() : nullptr);
+                            total > EMIT_CHUNK ? sl.emit_run.as<uint64_t>() : nullptr, sl.bounds.as<uint32_t>());
         map->next_attempt = total;
         if (rc == PM_OK) rc = stamp(map->t_emitted, nullptr, sl.stream);
-        if (rc == PM_OK) rc = build_index(map, sl);
+        if (rc == PM_OK) rc = build_index(map, sl, total > 0);
         if (rc == PM_OK && hipEventRecord(map->ready, sl.stream) != hipSuccess) rc = fail(PM_EHIP, "pm_map_create: hipEventRecord failed");
     }
     if (rc == PM_OK) { map->pending = true; if (attempts_used) rc = map_ready(map); }
@@ -983,6 +994,7 @@ static int gather_blocks(pm_ctx *ctx) {
     ctx->group_bounced = !(eb && eb[0] == '0');
     if (const char *v = getenv("PM_SP_CELL")) { double x = atof(v); if (x > 0.1 && x < 100) ctx->sp_cell = x; }
     if (const char *v = getenv("PM_SP_EST")) { double x = atof(v); if (x > 0.01 && x < 1000) ctx->sp_est = x; }
+    if (const char *v = getenv("PM_TILE_PARTS")) { int x = atoi(v); if (x >= 1 && x <= 4) ctx->tile_parts = x; }
     if (const char *v = getenv("PM_SP_MIN_RUN")) { int x = atoi(v); if (x >= 1 && x <= 64) ctx->sp_min_run = x; }
     if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] resident gather blocks: group kernel %d (%d per CU), per-query kernel %d (%d per CU), %d CUs\n", ctx->tile_blocks, per_cu_t,
                                     ctx->query_blocks, per_cu_q, cus);
@@ -1008,6 +1020,7 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
 // One frame, queued without a host wait: every count a later kernel needs (shade points, bounced pixels, groups, what the
 // group kernel leaves) stays on the device, launches are sized for the capacity of the queues, and the maps are waited for by
 // the streams (hipStreamWaitEvent), not by the host.  The host looks at the frame once, when it is over (render_impl).
+static uint32_t left_of(const Counters &c, int kind) { return c.n_left[kind][0] + c.n_left[kind][1] + c.n_left[kind][2] + c.n_left[kind][3]; }
 static int enqueue_frame(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_params *rp, const FrameParams &fp, uint32_t *d_pane, int owned, bool gathered[2]) {
     const int W = rp->width;
     Counters *d_ctr = ctx->ctr.as<Counters>();
@@ -1033,7 +1046,8 @@ static int enqueue_frame(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
     // The gather: groups of neighbouring shade points first (k_gather_tile), then one wave per shade point for what
     // the group kernel left and for the shade points of bounced pixels (k_gather).  Both kernels are launched with
     // as many blocks as the device keeps resident and draw their work from device counters.
-    HIPCHK(hipMemsetAsync(ctx->sched.p, 0, 6 * SCHED_WORDS * 4, ctx->stream));   // 64 work counters per gather launch
+    HIPCHK(hipMemsetAsync(ctx->sched.p, 0, N_SCHED * SCHED_WORDS * 4, ctx->stream));   // 64 work counters per gather launch
+    int n_sched = 0;
     uint32_t *sched = ctx->sched.as<uint32_t>();
     uint32_t *left = ctx->left.as<uint32_t>();
     const bool use_tiles = ctx->use_tiles;
@@ -1075,6 +1089,13 @@ static int enqueue_frame(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
     const uint32_t *zero = &d_ctr->pad;   // "nothing left": the third stream's launches have only the bounced range
     // the map whose build is already over goes first
     const bool global_late = gmap && gmap->pending && hipEventQuery(gmap->ready) != hipSuccess;
+    const uint32_t nparts = use_tiles ? (uint32_t)ctx->tile_parts : 1u;
+    auto per_query = [&](int kind, pm_map *map, hipStream_t on, const uint32_t *list, const uint32_t *count, int mode) {
+        uint32_t *sc = sched + (size_t)(n_sched++) * SCHED_WORDS;
+        if (kind == 0) hipLaunchKernelGGL(k_gather<0>, dim3(ctx->query_blocks), block, 0, on, map->view, q, list, count, d_ctr, mode, sc);
+        else hipLaunchKernelGGL(k_gather<1>, dim3(ctx->query_blocks), block, 0, on, map->view, q, list, count, d_ctr, mode, sc);
+    };
+    // first the waits for the maps, and on the third stream what needs no group kernel before it
     for (int turn = 0; turn < 2; turn++) {
         const int kind = global_late ? 1 - turn : turn;
         pm_map *map = kind == 0 ? gmap : cmap;
@@ -1087,30 +1108,41 @@ static int enqueue_frame(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
             if (!ctx->yield_known[map->kind >= 0 ? map->kind : 0] && map->kind >= 0) PMCHK(map_ready(map));   // first map of a scene: is it complete at all?
             else { HIPCHK(hipStreamWaitEvent(st, map->ready, 0)); HIPCHK(hipStreamWaitEvent(ctx->aux2, map->ready, 0)); }
         }
-        uint32_t *lk = left + (size_t)kind * q.cap, *nl = &d_ctr->n_left[kind];
-        float4 *strips = ctx->strips.as<float4>() + (size_t)kind * ctx->tile_blocks * TS_STRIDE;
         HIPCHK(hipEventRecord(ctx->ev_g[kind][0], st));
-        if (kind == 0) {
-            if (use_tiles) {
-                if (sec_mode == 1) hipLaunchKernelGGL(k_gather<0>, dim3(ctx->query_blocks), block, 0, ctx->aux2, map->view, q, lk, zero, d_ctr, 1, sched + 4 * SCHED_WORDS);
-                else hipLaunchKernelGGL(k_gather<0>, dim3(ctx->query_blocks), block, 0, ctx->aux2, map->view, q, ctx->sp_early.as<uint32_t>(), &d_ctr->n_early, d_ctr, 0, sched + 4 * SCHED_WORDS);
-                hipLaunchKernelGGL(k_gather_tile<0>, dim3(ctx->tile_blocks), dim3(64), 0, st, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sched, strips, dbg,
-                                   sorted, ctx->sp_groups.as<uint2>());
-            }
-            HIPCHK(hipEventRecord(ctx->ev_g[kind][1], st));
-            hipLaunchKernelGGL(k_gather<0>, dim3(ctx->query_blocks), block, 0, st, map->view, q, lk, nl, d_ctr, use_tiles ? 0 : 2, sched + SCHED_WORDS);
-        } else {
-            if (use_tiles) {
-                if (sec_mode == 1) hipLaunchKernelGGL(k_gather<1>, dim3(ctx->query_blocks), block, 0, ctx->aux2, map->view, q, lk, zero, d_ctr, 1, sched + 5 * SCHED_WORDS);
-                else hipLaunchKernelGGL(k_gather<1>, dim3(ctx->query_blocks), block, 0, ctx->aux2, map->view, q, ctx->sp_early.as<uint32_t>(), &d_ctr->n_early, d_ctr, 0, sched + 5 * SCHED_WORDS);
-                hipLaunchKernelGGL(k_gather_tile<1>, dim3(ctx->tile_blocks), dim3(64), 0, st, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sched + 2 * SCHED_WORDS, strips, dbg,
-                                   sorted, ctx->sp_groups.as<uint2>());
-            }
-            HIPCHK(hipEventRecord(ctx->ev_g[kind][1], st));
-            hipLaunchKernelGGL(k_gather<1>, dim3(ctx->query_blocks), block, 0, st, map->view, q, lk, nl, d_ctr, use_tiles ? 0 : 2, sched + 3 * SCHED_WORDS);
+        if (use_tiles) {
+            // beside the groups: the bounced pixels' shade points that are not grouped
+            if (sec_mode == 1) per_query(kind, map, ctx->aux2, left, zero, 1);
+            else per_query(kind, map, ctx->aux2, ctx->sp_early.as<uint32_t>(), &d_ctr->n_early, 0);
         }
-        HIPCHK(hipEventRecord(ctx->ev_g[kind][2], st));
         gathered[kind] = true;
+    }
+    // then the groups, part by part; what a part leaves is gathered per query on the third stream beside the next part, what
+    // the last part leaves behind it on its own stream
+    for (uint32_t part = 0; part < nparts; part++) {
+        for (int turn = 0; turn < 2; turn++) {
+            const int kind = global_late ? 1 - turn : turn;
+            pm_map *map = kind == 0 ? gmap : cmap;
+            if (!gathered[kind]) continue;
+            hipStream_t st = kind == 0 ? ctx->stream : ctx->aux;
+            float4 *strips = ctx->strips.as<float4>() + (size_t)kind * ctx->tile_blocks * TS_STRIDE;
+            uint32_t *lk = left + ((size_t)kind * 4 + part) * q.cap, *nl = &d_ctr->n_left[kind][part];
+            if (use_tiles) {
+                uint32_t *sc = sched + (size_t)(n_sched++) * SCHED_WORDS;
+                if (kind == 0) hipLaunchKernelGGL(k_gather_tile<0>, dim3(ctx->tile_blocks), dim3(64), 0, st, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sc, strips, dbg,
+                                                  sorted, ctx->sp_groups.as<uint2>(), part, nparts);
+                else hipLaunchKernelGGL(k_gather_tile<1>, dim3(ctx->tile_blocks), dim3(64), 0, st, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sc, strips, dbg,
+                                        sorted, ctx->sp_groups.as<uint2>(), part, nparts);
+            }
+            if (part + 1 < nparts) {
+                HIPCHK(hipEventRecord(ctx->ev_part[kind][part], st));
+                HIPCHK(hipStreamWaitEvent(ctx->aux2, ctx->ev_part[kind][part], 0));
+                per_query(kind, map, ctx->aux2, lk, nl, 0);
+            } else {
+                HIPCHK(hipEventRecord(ctx->ev_g[kind][1], st));
+                per_query(kind, map, st, lk, nl, use_tiles ? 0 : 2);
+                HIPCHK(hipEventRecord(ctx->ev_g[kind][2], st));
+            }
+        }
     }
     HIPCHK(hipEventRecord(ctx->ev_join2, ctx->aux2));
     HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join2, 0));
@@ -1148,7 +1180,7 @@ static int render_impl(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_
     PMCHK(ctx->clist.ensure(owned_px * 4));
     PMCHK(ctx->groups.ensure((size_t)owned * 2 * ((W + 7) / 8) * sizeof(uint2)));   // one group per 8x8 pixel tile: 2 tile rows per row block, ceil(W/8) columns
     PMCHK(gather_blocks(ctx));
-    PMCHK(ctx->sched.ensure(6 * SCHED_WORDS * 4 + 2 * 8192 * 16));
+    PMCHK(ctx->sched.ensure(N_SCHED * SCHED_WORDS * 4 + 2 * 8192 * 16));
     PMCHK(ctx->strips.ensure((size_t)2 * ctx->tile_blocks * TS_STRIDE * sizeof(float4)));
     PMCHK(ctx->sp_bounds.ensure(6 * 4));
     // Capacities the frame is launched for.  They start from what frames of this size usually need and only grow: a frame
@@ -1157,7 +1189,7 @@ static int render_impl(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_
     bool gathered[2] = {false, false};
     for (int attempt = 0;; attempt++) {
         PMCHK(ensure_sp(ctx, want_sp));
-        PMCHK(ctx->left.ensure((size_t)2 * ctx->sp_cap * 4 + 8));
+        PMCHK(ctx->left.ensure((size_t)8 * ctx->sp_cap * 4 + 8));   // per map and part of the group launches
         if (want_c > ctx->c_cap) { PMCHK(ctx->tab.ensure((size_t)want_c * 16 * sizeof(NodeEntry))); ctx->c_cap = want_c; }
         if (want_b > ctx->b_cap) {
             PMCHK(ctx->sp_keys_in.ensure((size_t)want_b * 8)); PMCHK(ctx->sp_keys_out.ensure((size_t)want_b * 8));
@@ -1207,7 +1239,7 @@ static int render_impl(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_
     Counters *d_ctr = ctx->ctr.as<Counters>();
     if (getenv("PM_DEBUG")) {
         fprintf(stderr, "[pm] shade points %u (primary %u), groups %u, left to the per-query gather: global %u caustic %u\n", n_sp, n_sp0,
-                hc.n_groups, hc.n_left[0], hc.n_left[1]);
+                hc.n_groups, left_of(hc, 0), left_of(hc, 1));
         fprintf(stderr, "[pm] bounced pixels' shade points in spatial order: %u, in %u groups; %u straight to the per-query kernel\n", n_sorted, hc.n_sgroups, hc.n_early);
         fprintf(stderr, "[pm] lanes handed over, by reason (few photons, spread, radius, |S|, no lane served, -, own shortfall): %u %u %u %u %u %u %u\n", hc.why[1], hc.why[2],
                 hc.why[3], hc.why[4], hc.why[5], hc.why[6], hc.why[7]);
@@ -1242,12 +1274,12 @@ static int render_impl(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_
         if (gathered[0]) {
             (void)hipEventElapsedTime(&stats->ms_gather_global, ctx->ev_g[0][0], ctx->ev_g[0][2]);
             (void)hipEventElapsedTime(&stats->ms_group_global, ctx->ev_g[0][0], ctx->ev_g[0][1]);
-            stats->grouped_global = n_primary_sp ? n_primary_sp - hc.n_left[0] - hc.n_early : 0u;
+            stats->grouped_global = n_primary_sp ? n_primary_sp - left_of(hc, 0) - hc.n_early : 0u;
         }
         if (gathered[1]) {
             (void)hipEventElapsedTime(&stats->ms_gather_caustic, ctx->ev_g[1][0], ctx->ev_g[1][2]);
             (void)hipEventElapsedTime(&stats->ms_group_caustic, ctx->ev_g[1][0], ctx->ev_g[1][1]);
-            stats->grouped_caustic = n_primary_sp ? n_primary_sp - hc.n_left[1] - hc.n_early : 0u;
+            stats->grouped_caustic = n_primary_sp ? n_primary_sp - left_of(hc, 1) - hc.n_early : 0u;
         }
         (void)hipEventElapsedTime(&stats->ms_resolve, ctx->ev[5], ctx->ev[6]);
         (void)hipEventElapsedTime(&stats->ms_total, ctx->ev[0], ctx->ev[6]);

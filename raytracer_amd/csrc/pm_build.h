@@ -5,6 +5,7 @@
 #include "pm_knn.h"
 #include "pm_morton.h"
 #include "pm_grid.h"
+#include "pm_sort.h"
 #include "../../include/raytracer_amd.h"
 
 namespace pm {
@@ -100,28 +101,26 @@ __global__ __launch_bounds__(256) void k_emit(SceneView gs, int map_kind, uint64
 // exclusive scan of nb block counts by one 1024-thread block; offs[nb] = total.  running != NULL: a map emitted in several
 // ranges chains them on the device -- the scan starts from *running (the successes of the ranges before) and leaves
 // *running at the new total, so the scatter that follows appends behind the earlier ranges without the host knowing a count.
-__global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t *counts, uint64_t *offs, uint32_t nb, uint64_t *running) {
-    __shared__ uint64_t buf[1024];
-    __shared__ uint64_t carry;
-    if (threadIdx.x == 0) carry = running ? *running : 0;
+// Every thread sums a run of consecutive counts, the 1024 sums are scanned with wave shuffles, the runs are written out.
+// bounds_init != NULL: the six words of the index build's bounds are reset here (minima all ones, maxima zero), which
+// saves the build a copy from the host.
+__global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t *counts, uint64_t *offs, uint32_t nb, uint64_t *running, uint32_t *bounds_init) {
+    __shared__ uint64_t wsum[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (bounds_init && threadIdx.x < 6) bounds_init[threadIdx.x] = threadIdx.x < 3 ? 0xFFFFFFFFu : 0u;
+    const uint32_t per = (nb + 1023u) / 1024u, lo = min(threadIdx.x * per, nb), hi = min(lo + per, nb);
+    uint64_t mine = 0;
+    for (uint32_t i = lo; i < hi; i++) mine += counts[i];
+    uint64_t inc = mine;
+    for (int s = 1; s < 64; s <<= 1) { uint64_t y = __shfl_up(inc, s); if (lane >= s) inc += y; }
+    if (lane == 63) wsum[wave] = inc;
     __syncthreads();
-    for (uint32_t base = 0; base < nb; base += 1024) {
-        uint32_t i = base + threadIdx.x;
-        uint64_t v = i < nb ? counts[i] : 0;
-        buf[threadIdx.x] = v;
-        __syncthreads();
-        for (int s = 1; s < 1024; s <<= 1) {
-            uint64_t add = threadIdx.x >= (unsigned)s ? buf[threadIdx.x - s] : 0;
-            __syncthreads();
-            buf[threadIdx.x] += add;
-            __syncthreads();
-        }
-        if (i < nb) offs[i] = carry + buf[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += buf[1023];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { offs[nb] = carry; if (running) *running = carry; }
+    uint64_t before = running ? *running : 0;
+    for (int w = 0; w < wave; w++) before += wsum[w];
+    uint64_t run = before + inc - mine;
+    for (uint32_t i = lo; i < hi; i++) { offs[i] = run; run += counts[i]; }
+    __syncthreads();                                  // every thread has read *running
+    if (threadIdx.x == 1023) { offs[nb] = run; if (running) *running = run; }
 }
 
 __global__ __launch_bounds__(256) void k_emit_scatter(const pm_photon *tmp, const uint8_t *flag, const uint64_t *offs, uint64_t count,
@@ -194,61 +193,109 @@ __global__ __launch_bounds__(256) void k_bounds(const pm_photon *ph, long long n
     }
 }
 
-__global__ __launch_bounds__(256) void k_morton(const pm_photon *ph, long long n, const uint32_t *bounds, uint64_t *keys, uint32_t *vals) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float p[3] = {ph[i].x, ph[i].y, ph[i].z};
+// Keys of the photons (blocks of SORT_TILE, the sort's own tiling), the sort's first histogram (digit 0 of every block:
+// k_sort_count of pass 0, pm_sort.h) and, by the first thread, the quantisation grid the queries need (pm_knn.h, MapView).
+__global__ __launch_bounds__(256) void k_morton(const pm_photon *ph, long long n, const uint32_t *bounds, uint64_t *keys, uint32_t *vals, uint32_t nblk,
+                                                 uint32_t *table, GridParams *g) {
+    __shared__ uint32_t hist[SORT_DIGITS];
+    for (int d = threadIdx.x; d < SORT_DIGITS; d += 256) hist[d] = 0u;
     // one cubic grid over the largest extent (anisotropic scaling would distort the curve's locality)
-    float ext = 0.f;
-    for (int a = 0; a < 3; a++) ext = fmaxf(ext, ord2f(bounds[3 + a]) - ord2f(bounds[a]));
-    uint32_t qv[3];
-    for (int a = 0; a < 3; a++) qv[a] = quant21(p[a], ord2f(bounds[a]), ext);
-    keys[i] = morton63(qv[0], qv[1], qv[2]);     // linear octree: aligned cells are contiguous key ranges
-    vals[i] = (uint32_t)i;
-}
-
-// the quantisation grid of a map, from the bounds: what the queries need (pm_knn.h, MapView)
-__global__ void k_grid_params(const uint32_t *bounds, GridParams *g) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float ext = 0.f;
-    for (int a = 0; a < 3; a++) { g->glo[a] = ord2f(bounds[a]); ext = fmaxf(ext, ord2f(bounds[3 + a]) - ord2f(bounds[a])); }
-    g->gext = ext;
-    g->gu = (double)ext / 2097152.0;
-}
-
-// cell start tables of the linear octree: entry c of level l = first sorted photon whose key prefix is >= c
-__global__ __launch_bounds__(256) void k_cell_tables(const uint64_t *keys, long long n, uint32_t *cells, int lmax) {
-    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= cell_off(lmax + 1)) return;
-    int l = 0;
-    while (l < lmax && t >= cell_off(l + 1)) l++;
-    unsigned long long c = (unsigned long long)(t - cell_off(l));
-    long long lo = 0, hi = n;
-    if (c >> (3 * l)) lo = n;   // the sentinel entry 8^l
-    else {
-        unsigned long long target = l == 0 ? 0ULL : c << (63 - 3 * l);
-        while (lo < hi) { long long mid = (lo + hi) >> 1; if (keys[mid] < target) lo = mid + 1; else hi = mid; }
+    float lo[3], ext = 0.f;
+    for (int a = 0; a < 3; a++) { lo[a] = ord2f(bounds[a]); ext = fmaxf(ext, ord2f(bounds[3 + a]) - lo[a]); }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { g->glo[0] = lo[0]; g->glo[1] = lo[1]; g->glo[2] = lo[2]; g->gext = ext; g->gu = (double)ext / 2097152.0; }
+    __syncthreads();
+    const long long base = (long long)blockIdx.x * SORT_TILE, end = min(base + (long long)SORT_TILE, n);
+    for (long long i = base + threadIdx.x; i < end; i += 256) {
+        const uint64_t k = morton63(quant21(ph[i].x, lo[0], ext), quant21(ph[i].y, lo[1], ext), quant21(ph[i].z, lo[2], ext));
+        keys[i] = k;                                // linear octree: aligned cells are contiguous key ranges
+        vals[i] = (uint32_t)i;
+        atomicAdd(&hist[sort_digit(k, SORT_FIRST_BIT)], 1u);
     }
-    cells[t] = (uint32_t)lo;
+    __syncthreads();
+    for (int d = threadIdx.x; d < SORT_DIGITS; d += 256) table[(size_t)d * nblk + blockIdx.x] = hist[d];
+}
+
+// ---- the cell table of the linear octree: cells[c] = first sorted photon of cell c of the FINEST table level lmax (8^lmax + 1
+// entries; the last one is n).  A cell of a coarser level l is the aligned run of 8^(lmax - l) fine cells, so its range is
+// read from the same table (pm_grid.h, cell_range).  Built from the photon side: the table is preset to all ones, the first
+// photon of every occupied cell writes its index (k_permute), and the empty cells take the start of the next occupied one:
+// a suffix minimum, in two launches (block minima; then every block looks right for the first block that has one).
+constexpr int FILL_TILE = 2048;                          // table entries per block of the fill (256 threads x 8)
+__global__ __launch_bounds__(256) void k_fill_mins(const uint32_t *cells, long long n_entries, uint32_t *bmin) {
+    __shared__ uint32_t part[4];
+    const long long base = (long long)blockIdx.x * FILL_TILE;
+    uint32_t m = 0xFFFFFFFFu;
+    for (int j = threadIdx.x; j < FILL_TILE; j += 256) { const long long i = base + j; if (i < n_entries) m = min(m, cells[i]); }
+    for (int s = 1; s < 64; s <<= 1) m = min(m, (uint32_t)__shfl_xor((int)m, s));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) bmin[blockIdx.x] = min(min(part[0], part[1]), min(part[2], part[3]));
+}
+__global__ __launch_bounds__(256) void k_fill_cells(uint32_t *cells, long long n_entries, const uint32_t *bmin, uint32_t nblk) {
+    __shared__ uint32_t part[4], wmin[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the first occupied entry to the right of this block (starts only grow to the right: the minimum is the nearest)
+    uint32_t m = 0xFFFFFFFFu;
+    for (uint32_t b0 = blockIdx.x + 1; b0 < nblk; b0 += 256) {
+        const uint32_t b = b0 + threadIdx.x;
+        m = b < nblk ? bmin[b] : 0xFFFFFFFFu;
+        if (__syncthreads_or(m != 0xFFFFFFFFu)) break;
+    }
+    for (int s = 1; s < 64; s <<= 1) m = min(m, (uint32_t)__shfl_xor((int)m, s));
+    if (lane == 0) part[wave] = m;
+    // this thread's eight consecutive entries; the minimum of everything to its right inside the block by wave shuffles
+    const long long at = (long long)blockIdx.x * FILL_TILE + (long long)threadIdx.x * 8;
+    uint32_t v[8], mine = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { v[j] = at + j < n_entries ? cells[at + j] : 0xFFFFFFFFu; mine = min(mine, v[j]); }
+    uint32_t suf = mine;                                 // inclusive suffix minimum over the lanes of the wave
+    for (int s = 1; s < 64; s <<= 1) { const uint32_t y = (uint32_t)__shfl_down((int)suf, s); if (lane + s < 64) suf = min(suf, y); }
+    if (lane == 0) wmin[wave] = suf;
+    uint32_t right = (uint32_t)__shfl_down((int)suf, 1);
+    if (lane == 63) right = 0xFFFFFFFFu;
+    __syncthreads();
+    for (int w = wave + 1; w < 4; w++) right = min(right, wmin[w]);
+    right = min(right, min(min(part[0], part[1]), min(part[2], part[3])));
+#pragma unroll
+    for (int j = 7; j >= 0; j--) {
+        if (v[j] == 0xFFFFFFFFu) v[j] = right; else right = v[j];
+        if (at + j < n_entries) cells[at + j] = v[j];
+    }
 }
 
 // ---- tight boxes of the octree cells (pm_grid.h): per cell and axis the lowest and highest occupied 1/1024 slice,
-// 6 x 10 bits in one 64-bit word.  Photon sets are flat (they lie on surfaces) while cells are cubes: the box of a
-// floor cell is a slab, and a query ball that dips into the cube without reaching the floor can drop the cell.
+// 6 x 10 bits in one 64-bit word; all ones for an empty cell.  Photon sets are flat (they lie on surfaces) while cells are
+// cubes: the box of a floor cell is a slab, and a query ball that dips into the cube without reaching the floor can drop the cell.
+constexpr uint64_t BOX_EMPTY = ~0ULL;
 __device__ inline uint64_t pack_box(const uint32_t lo[3], const uint32_t hi[3]) {
     uint64_t w = 0;
     for (int a = 0; a < 3; a++) w |= ((uint64_t)lo[a] << (20 * a)) | ((uint64_t)hi[a] << (20 * a + 10));
     return w;
 }
-// finest table level: one lane per cell (most cells hold a handful of photons or none); a cell with more than 32
-// photons is then reduced by the whole wave
-__global__ __launch_bounds__(256) void k_cell_boxes_fine(const float4 *pos4, const uint32_t *cells, int lmax, const uint32_t *bounds, uint64_t *cbox) {
-    const long long ncell = 1LL << (3 * lmax);
-    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// a cell's box from its eight children's: union of the non-empty ones, halved into the parent's 1/1024 slices
+__device__ inline uint64_t box_of_children(const uint64_t *child) {
+    uint32_t lo[3] = {1023u, 1023u, 1023u}, hi[3] = {0u, 0u, 0u};
+    bool any = false;
+    for (int j = 0; j < 8; j++) {
+        const uint64_t w = child[j];
+        if (w == BOX_EMPTY) continue;
+        any = true;
+        for (int a = 0; a < 3; a++) {
+            uint32_t half = ((uint32_t)(j >> a) & 1u) * 512u;
+            lo[a] = min(lo[a], half + (((uint32_t)(w >> (20 * a)) & 1023u) >> 1));
+            hi[a] = max(hi[a], half + (((uint32_t)(w >> (20 * a + 10)) & 1023u) >> 1));
+        }
+    }
+    return any ? pack_box(lo, hi) : BOX_EMPTY;
+}
+// The finest level and the `depth` (<= 3) levels above it in one launch: a block takes one cell of level lmax - depth, works
+// out the boxes of its 8^depth fine cells from their photons (one lane per cell -- most cells hold a handful of photons
+// or none; a cell with more than 32 is reduced by the whole wave, one with more than 512 is a dense blob that queries
+// split further anyway: its box is the whole cube) and folds them up level by level through LDS.
+__global__ __launch_bounds__(256) void k_cell_boxes_tree(const float4 *pos4, const uint32_t *cells, int lmax, int depth, const uint32_t *bounds, uint64_t *cbox) {
+    __shared__ uint64_t lbox[512 + 64 + 8 + 1];
     const int lane = threadIdx.x & 63;
-    const uint32_t *tab = cells + cell_off(lmax);
-    uint32_t first = 0, end = 0;
-    if (c < ncell) { first = tab[c]; end = tab[c + 1]; }
+    const int nfine = 1 << (3 * depth);
     float glo[3] = {ord2f(bounds[0]), ord2f(bounds[1]), ord2f(bounds[2])}, ext = 0.f;
     for (int a = 0; a < 3; a++) ext = fmaxf(ext, ord2f(bounds[3 + a]) - glo[a]);
     const int sh = 21 - lmax;   // >= 13
@@ -259,59 +306,58 @@ __global__ __launch_bounds__(256) void k_cell_boxes_fine(const float4 *pos4, con
             lo[a] = min(lo[a], sub); hi[a] = max(hi[a], sub);
         }
     };
-    // a cell holding many hundreds of photons is a dense blob that queries split further anyway: its box is the whole cube
-    const bool huge = end - first > 512u;
-    if (huge) { const uint32_t lo[3] = {0u, 0u, 0u}, hi[3] = {1023u, 1023u, 1023u}; cbox[box_off(lmax) + c] = pack_box(lo, hi); }
-    const bool big = !huge && end - first > 32u;
-    if (end > first && !big && !huge) {
-        uint32_t lo[3] = {1023u, 1023u, 1023u}, hi[3] = {0u, 0u, 0u};
-        for (uint32_t i = first; i < end; i++) slice(pos4[i], lo, hi);
-        cbox[box_off(lmax) + c] = pack_box(lo, hi);
-    }
-    for (unsigned long long todo = __ballot(big); todo; todo &= todo - 1) {
-        const int src = __ffsll((long long)todo) - 1;
-        const uint32_t f = (uint32_t)__shfl((int)first, src), e = (uint32_t)__shfl((int)end, src);
-        uint32_t lo[3] = {1023u, 1023u, 1023u}, hi[3] = {0u, 0u, 0u};
-        for (uint32_t i = f + (uint32_t)lane; i < e; i += 64u) slice(pos4[i], lo, hi);
-        for (int a = 0; a < 3; a++)
-            for (int s = 1; s < 64; s <<= 1) { lo[a] = min(lo[a], (uint32_t)__shfl_xor((int)lo[a], s)); hi[a] = max(hi[a], (uint32_t)__shfl_xor((int)hi[a], s)); }
-        if (lane == src) cbox[box_off(lmax) + c] = pack_box(lo, hi);
-    }
-}
-// level l from level l + 1: union of the non-empty children, halved into the parent's 1/1024 slices
-__device__ inline void cell_box_up(const uint32_t *cells, int l, long long c, uint64_t *cbox) {
-    const uint32_t *tab = cells + cell_off(l + 1);
-    uint32_t lo[3] = {1023u, 1023u, 1023u}, hi[3] = {0u, 0u, 0u};
-    bool any = false;
-    for (int j = 0; j < 8; j++) {
-        long long k = 8 * c + j;
-        if (tab[k] == tab[k + 1]) continue;
-        any = true;
-        uint64_t w = cbox[box_off(l + 1) + k];
-        for (int a = 0; a < 3; a++) {
-            uint32_t half = ((uint32_t)(j >> a) & 1u) * 512u;
-            lo[a] = min(lo[a], half + (((uint32_t)(w >> (20 * a)) & 1023u) >> 1));
-            hi[a] = max(hi[a], half + (((uint32_t)(w >> (20 * a + 10)) & 1023u) >> 1));
+    for (int j0 = 0; j0 < nfine; j0 += 256) {            // (a wave runs a round whole or not at all: the ballots below are whole)
+        const int j = j0 + threadIdx.x;
+        if (j0 + (int)(threadIdx.x & ~63u) >= nfine) break;
+        const long long c = (long long)blockIdx.x * nfine + j;
+        uint32_t first = 0, end = 0;
+        if (j < nfine) { first = cells[c]; end = cells[c + 1]; }
+        uint64_t w = BOX_EMPTY;
+        const bool huge = end - first > 512u, big = !huge && end - first > 32u;
+        if (huge) { const uint32_t lo[3] = {0u, 0u, 0u}, hi[3] = {1023u, 1023u, 1023u}; w = pack_box(lo, hi); }
+        else if (end > first && !big) {
+            uint32_t lo[3] = {1023u, 1023u, 1023u}, hi[3] = {0u, 0u, 0u};
+            for (uint32_t i = first; i < end; i++) slice(pos4[i], lo, hi);
+            w = pack_box(lo, hi);
         }
+        for (unsigned long long todo = __ballot(big); todo; todo &= todo - 1) {
+            const int src = __ffsll((long long)todo) - 1;
+            const uint32_t f = (uint32_t)__shfl((int)first, src), e = (uint32_t)__shfl((int)end, src);
+            uint32_t lo[3] = {1023u, 1023u, 1023u}, hi[3] = {0u, 0u, 0u};
+            for (uint32_t i = f + (uint32_t)lane; i < e; i += 64u) slice(pos4[i], lo, hi);
+            for (int a = 0; a < 3; a++)
+                for (int s = 1; s < 64; s <<= 1) { lo[a] = min(lo[a], (uint32_t)__shfl_xor((int)lo[a], s)); hi[a] = max(hi[a], (uint32_t)__shfl_xor((int)hi[a], s)); }
+            if (lane == src) w = pack_box(lo, hi);
+        }
+        if (j < nfine) { cbox[box_off(lmax) + c] = w; lbox[j] = w; }
     }
-    if (any) cbox[box_off(l) + c] = pack_box(lo, hi);
+    // levels lmax - 1 .. lmax - depth of this block's subtree
+    int below = 0, count = nfine;                        // offset and size of the level below in lbox
+    for (int d = 1; d <= depth; d++) {
+        __syncthreads();
+        const int mine = count >> 3, at = below + count;
+        for (int j = threadIdx.x; j < mine; j += 256) {
+            const uint64_t w = box_of_children(&lbox[below + 8 * j]);
+            lbox[at + j] = w;
+            cbox[box_off(lmax - d) + (long long)blockIdx.x * mine + j] = w;
+        }
+        below = at; count = mine;
+    }
 }
-__global__ __launch_bounds__(256) void k_cell_boxes_up(const uint32_t *cells, int l, uint64_t *cbox) {
-    long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < (1LL << (3 * l))) cell_box_up(cells, l, c, cbox);
-}
-// levels ltop, ltop - 1, ..., 0 in one block (8^ltop <= 512 cells): one launch instead of one per level.  A small block:
-// beside wide kernels of the frame a 16-wave block waits a long time for a compute unit with room for all of it.
-__global__ __launch_bounds__(256) void k_cell_boxes_top(const uint32_t *cells, int ltop, uint64_t *cbox) {
+// levels ltop, ltop - 1, ..., 0 in one block (the levels above the subtrees of k_cell_boxes_tree): one launch instead of one per
+// level.  A small block: beside wide kernels of the frame a 16-wave block waits a long time for a compute unit with room for all of it.
+__global__ __launch_bounds__(256) void k_cell_boxes_top(int ltop, uint64_t *cbox) {
     for (int l = ltop; l >= 0; l--) {
-        for (long long c = threadIdx.x; c < (1LL << (3 * l)); c += blockDim.x) cell_box_up(cells, l, c, cbox);
+        for (long long c = threadIdx.x; c < (1LL << (3 * l)); c += blockDim.x) cbox[box_off(l) + c] = box_of_children(&cbox[box_off(l + 1) + 8 * c]);
         __threadfence_block();
         __syncthreads();
     }
 }
 
-// sorted order -> the two 16-byte streams the gather reads
-__global__ __launch_bounds__(256) void k_permute(const pm_photon *ph, const uint32_t *order, long long n, float4 *pos4, uint4 *rest) {
+// sorted order -> the two 16-byte streams the gather reads; and the first photon of every occupied cell of the finest
+// table level enters its index into the cell table (preset to all ones; the last entry is n)
+__global__ __launch_bounds__(256) void k_permute(const pm_photon *ph, const uint32_t *order, const uint64_t *keys, long long n, int lmax, float4 *pos4, uint4 *rest,
+                                                  uint32_t *cells) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t o = order[i];
@@ -319,6 +365,10 @@ __global__ __launch_bounds__(256) void k_permute(const pm_photon *ph, const uint
     uint4 a = rec[0], b = rec[1];   // a = x y z power ; b = dx dy dz bounce
     pos4[i] = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(o));
     rest[i] = make_uint4(b.x, b.y, b.z, a.w);
+    const int ks = 63 - 3 * lmax;
+    const uint64_t c = lmax ? keys[i] >> ks : 0ULL;
+    if (i == 0 || (lmax ? keys[i - 1] >> ks : 0ULL) != c) cells[c] = (uint32_t)i;
+    if (i == 0) cells[1LL << (3 * lmax)] = (uint32_t)n;
 }
 
 }  // namespace pm

@@ -44,9 +44,10 @@ constexpr int GRID_MAX_LEVEL = 10;   // cells are not split below this level: ph
 // cell is a sub-range of [plo, pend) (its parent's range): two binary searches on the sorted keys
 __device__ inline void cell_range(const MapView &m, int level, uint64_t key, uint32_t plo, uint32_t pend, uint32_t &first, uint32_t &cnt) {
     if (level <= m.lmax) {
-        const uint32_t *tab = m.cells + cell_off(level);
-        first = tab[key];
-        cnt = tab[key + 1] - first;
+        // one table, of the finest level: a coarser cell is an aligned run of its entries
+        const int up = 3 * (m.lmax - level);
+        first = m.cells[key << up];
+        cnt = m.cells[(key + 1) << up] - first;
         return;
     }
     const int ks = 63 - 3 * level;

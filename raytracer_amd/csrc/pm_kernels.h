@@ -29,7 +29,7 @@ struct FrameParams {
     int rank, world;
 };
 
-struct Counters { uint32_t n_sp, n_complex, n_secondary, n_groups, n_left[2], pad, n_sgroups, n_early, n_pieces, overflow, n_sp0, n_bounced, done_primary, done_secondary; uint32_t why[8]; unsigned long long tphase[8]; uint32_t ghist[2][32]; };   // n_left[k]: shade points left to the per-query gather of map k
+struct Counters { uint32_t n_sp, n_complex, n_secondary, n_groups, n_left[2][4], pad, n_sgroups, n_early, n_pieces, overflow, n_sp0, n_bounced, done_primary, done_secondary; uint32_t why[8]; unsigned long long tphase[8]; uint32_t ghist[2][32]; };   // n_left[k][p]: shade points that part p of map k's group launches left to the per-query gather
 
 // The frame's counts live on the device: nothing of a frame waits for the host.  n_sp0 = shade points of primary hits (slots
 // 0 .. n_sp0, grouped by pixel tile), written by k_mark_primary behind k_primary; n_bounced = shade points of bounced pixels
@@ -450,7 +450,7 @@ static_assert(SCHED_CHUNK % PM_GATHER_GROUP == 0, "a draw must not straddle two 
 struct WorkDraw {
     uint32_t xcd, sub, tries;
     __device__ WorkDraw() : xcd(blockIdx.x & 7), sub((blockIdx.x >> 3) & 7), tries(0) {}
-    __device__ bool next(uint32_t *sched, uint32_t n_items, uint32_t group, uint32_t &i0, uint32_t &i1) {
+    __device__ bool next(uint32_t *sched, uint32_t n_items, uint32_t group, uint32_t &i0, uint32_t &i1) {   // items 0 .. n_items
         while (tries < 8) {
             const uint32_t c = xcd + 8 * sub;
             uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_draw(&sched[c * SCHED_STRIDE]));
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) void k_gather(MapView m_in, SPQueue q, const u
 // cannot be gathered as a group appends its slots to `left` for k_gather.
 template <int KIND>
 __global__ __launch_bounds__(64) void k_gather_tile(MapView m_in, SPQueue q, const uint2 *groups, const Counters *ctr, uint32_t *left, uint32_t *n_left,
-                                                    uint32_t *sched, float4 *strips, int dbg, const uint32_t *sorted, const uint2 *sgroups) {
+                                                    uint32_t *sched, float4 *strips, int dbg, const uint32_t *sorted, const uint2 *sgroups, uint32_t part, uint32_t nparts) {
     MapView m = m_in;
     load_grid(m);
     __shared__ TileBuf tb;
@@ -524,10 +524,14 @@ __global__ __launch_bounds__(64) void k_gather_tile(MapView m_in, SPQueue q, con
     const Strip S(reinterpret_cast<float *>(strips + (size_t)blockIdx.x * TS_STRIDE));   // this wave's strip for the shared candidate set
     double *out = KIND == 0 ? q.rad_g : q.rad_c;
     // the groups of the pixel tiles, then the groups of `sorted` (shade points of bounced pixels in spatial order)
+    // The groups are cut into `nparts` launches: what one part leaves is gathered per query (on another stream) while the next
+    // part runs, so that only the last part's leftovers are gathered with nothing beside them.
     const uint32_t n_tiles = ctr->n_groups, n_groups = n_tiles + ctr->n_sgroups;
+    const uint32_t g_lo = (uint32_t)((unsigned long long)n_groups * part / nparts), g_hi = (uint32_t)((unsigned long long)n_groups * (part + 1u) / nparts);
     WorkDraw wd;
     uint32_t i0, i1;
-    while (wd.next(sched, n_groups, 1u, i0, i1)) {
+    while (wd.next(sched, g_hi - g_lo, 1u, i0, i1)) {
+        i0 += g_lo;
 #ifdef PM_TILE_STAMPS
         const unsigned long long tg0 = __builtin_amdgcn_s_memtime();
 #endif

@@ -33,8 +33,8 @@ struct MapView {
     const uint4 *rest;           // sorted order: bits(dx), bits(dy), bits(dz), power[0..3]
     // linear octree (pm_grid.h): per-level cell start tables over the key-sorted photons
     const uint64_t *keys;        // sorted 63-bit Morton keys (levels below lmax are resolved by binary search)
-    const uint32_t *cells;       // level l occupies [cell_off(l), cell_off(l) + 8^l] (8^l + 1 entries)
-    const uint64_t *cbox;        // level l occupies [box_off(l), box_off(l) + 8^l): occupied 1/1024 slices of each non-empty cell
+    const uint32_t *cells;       // first photon of every cell of level lmax (8^lmax + 1 entries); coarser cells are aligned runs of it
+    const uint64_t *cbox;        // level l occupies [box_off(l), box_off(l) + 8^l): occupied 1/1024 slices of each cell (all ones: empty)
     int lmax;                    // finest level
     float glo[3], gext;          // cubic quantisation grid: fine index = (p - glo) / gext * 2^21
     double gu;                   // size of a fine unit: gext / 2^21
@@ -46,7 +46,6 @@ __device__ inline void load_grid(MapView &m) {
     if (m.n <= 0) return;
     m.glo[0] = m.grid->glo[0]; m.glo[1] = m.grid->glo[1]; m.glo[2] = m.grid->glo[2]; m.gext = m.grid->gext; m.gu = m.grid->gu;
 }
-__host__ __device__ inline long long cell_off(int l) { return (((1LL << (3 * l)) - 1) / 7) + l; }
 __host__ __device__ inline long long box_off(int l) { return ((1LL << (3 * l)) - 1) / 7; }
 
 // per-wave LDS working set

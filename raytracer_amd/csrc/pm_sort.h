@@ -134,8 +134,9 @@ inline size_t sort_scratch_words(uint32_t n_host) { return (size_t)SORT_DIGITS *
 
 // Sorts (keys_a, vals_a)[0 .. n) into (keys_b, vals_b); both pairs of buffers are overwritten.  n = n_host, or *n_dev when
 // n_dev is not NULL (then n_host is the capacity the launches are sized for).  Nothing waits for the device.
+// first_counted: the histogram of pass 0 is in the table already (the kernel that made the keys counted them: k_morton).
 inline hipError_t radix_sort_pairs_30(hipStream_t stream, uint64_t *keys_a, uint32_t *vals_a, uint64_t *keys_b, uint32_t *vals_b, uint32_t *scratch,
-                                      uint32_t n_host, const uint32_t *n_dev) {
+                                      uint32_t n_host, const uint32_t *n_dev, bool first_counted = false) {
     if (n_host == 0) return hipSuccess;
     const uint32_t nblk = (n_host + SORT_TILE - 1) / SORT_TILE;
     uint32_t *table = scratch, *rowsum = scratch + (size_t)SORT_DIGITS * nblk;
@@ -143,7 +144,7 @@ inline hipError_t radix_sort_pairs_30(hipStream_t stream, uint64_t *keys_a, uint
     uint32_t *vin = vals_a, *vout = vals_b;
     for (int p = 0; p < SORT_PASSES; p++) {
         const int shift = SORT_FIRST_BIT + SORT_BITS * p;
-        hipLaunchKernelGGL(k_sort_count, dim3(nblk), dim3(256), 0, stream, kin, n_host, n_dev, shift, nblk, table);
+        if (p > 0 || !first_counted) hipLaunchKernelGGL(k_sort_count, dim3(nblk), dim3(256), 0, stream, kin, n_host, n_dev, shift, nblk, table);
         hipLaunchKernelGGL(k_sort_rows, dim3(SORT_DIGITS / 4), dim3(256), 0, stream, table, nblk, rowsum);
         hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(256), 0, stream, kin, vin, n_host, n_dev, shift, nblk, table, rowsum, kout, vout);
         uint64_t *tk = kin; kin = kout; kout = tk;
