@@ -33,50 +33,78 @@ WORKLOAD = {"default": "default Cornell scene", "spheres10k": "five walls + 10,0
             "caustics": "five walls + five glass spheres (BASELINE config 4 scene),"}
 
 
-def latest_pmc_summary():
-    """profiles/rNN/pmc_per_dispatch_avg.json of the latest round that has one."""
-    import glob
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", "pmc_per_dispatch_avg.json")))
-    return found[-1] if found else os.path.join(ROOT, "profiles", "r01", "pmc_per_dispatch_avg.json")
-
-
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed PMC passes of this same command (tools/profile_bench.sh:
-    FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs; rocprofv3 reports KB; gfx950 correction: FETCH_SIZE tallies the
-    128-byte read requests at 64 bytes, so it is doubled -- MI355X_MICROARCH.md, HBM section)."""
-    path = latest_pmc_summary()
-    try:
-        with open(path) as f:
-            pmc = json.load(f)
-        for name, c in pmc.items():
-            if kernel in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, f"2 x FETCH_SIZE + WRITE_SIZE of {os.path.relpath(path, ROOT)} (not collected live)"
-    except (OSError, ValueError):
-        pass
-    return None, "no PMC summary found"
-
-
-# One SIMD issues an FP64 wave-instruction every ~2.2 ns when all of them are busy (profiles/r01/valu_rates.txt): 1024 SIMDs.
+# One SIMD issues an FP64 wave-instruction every ~2.2 ns when all of them are busy (tools/microbench/valu_rates.hip, profiles/r01/valu_rates.txt): 1024 SIMDs.
 VALU_PEAK_GINSTR_S = 1024 / 2.2
+# FP64 vector peak 78.6 TFLOP/s counts an FMA as two; contraction is off here (bit-exactness), so 39.3 T non-fused flop/s
+FP64_PEAK_TFLOPS = 39.3
+FLOP_PER_SPHERE_TEST, FLOP_PER_PLANE_TEST = 22, 6
+PMC_PASSES = (("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES"), ("FETCH_SIZE",), ("WRITE_SIZE",))   # FETCH_SIZE and WRITE_SIZE do not fit one pass
 
 
-def pmc_valu_issue(kernel, launch_ms):
-    """What actually bounds the gather kernels: vector instructions issued per second, from the
-    committed SQ_INSTS_VALU count of one launch of `kernel` over the launch time measured live, against the measured
-    issue rate of the whole device.  The other map's kernel shares the device during that time."""
-    path = latest_pmc_summary()
-    try:
-        with open(path) as f:
-            pmc = json.load(f)
-        for name, c in pmc.items():
-            if kernel in name and "SQ_INSTS_VALU" in c and launch_ms > 0:
-                ach = c["SQ_INSTS_VALU"] / (launch_ms * 1e-3) / 1e9
-                return {"achieved": ach, "peak": VALU_PEAK_GINSTR_S, "unit": "G wave-instr/s", "frac": ach / VALU_PEAK_GINSTR_S,
-                        "note": f"SQ_INSTS_VALU per launch from {os.path.relpath(path, ROOT)} (default scene; not collected live) "
-                                "/ live launch time; peak = 1024 SIMDs x one FP64 instruction per 2.2 ns (profiles/r01/valu_rates.txt); "
-                                "the two maps' kernels run side by side, each taking its share of that peak"}
-    except (OSError, ValueError):
-        pass
+def under_profiler():
+    return any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+
+
+def live_pmc(args):
+    """Counters of THIS build on THIS box, collected now: one rocprofv3 --pmc pass per counter set (as MI355X_MICROARCH.md
+    prescribes) over a short run of this same script and workload, as child processes.  Returns ({kernel: {counter: average
+    per launch}}, note); ({}, why) when the profiler is not there or a pass fails -- the line then carries nulls, never a
+    number from an earlier build."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    tool = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(tool):
+        return {}, "rocprofv3 not found"
+    if under_profiler():
+        return {}, "already running under a profiler"
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pmc", "--scene", args.scene,
+             "--width", str(args.width), "--height", str(args.height), "--photons", str(args.photons), "--seed", str(args.seed)]
+    acc = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for n, counters in enumerate(PMC_PASSES):
+        out = tempfile.mkdtemp(prefix="pm_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([tool, "--output-format", "csv", "--pmc", *counters, "-d", out, "-o", "pmc", "--"] + child,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {}, f"rocprofv3 pass {n + 1} ({' '.join(counters)}) failed: {(r.stderr or r.stdout)[-200:]}"
+            per = {}
+            for path in files:
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        key = (row["Kernel_Name"].split("(")[0].replace("void ", ""), row["Dispatch_Id"], row["Counter_Name"])
+                        per[key] = per.get(key, 0.0) + float(row["Counter_Value"])
+            lists = {}
+            for (k, _, c), v in per.items():
+                lists.setdefault((k, c), []).append(v)
+            for (k, c), v in lists.items():
+                acc.setdefault(k, {})[c] = sum(v) / len(v)
+                acc[k]["launches_" + c] = len(v)
+        except (OSError, subprocess.SubprocessError, ValueError, KeyError) as e:
+            return {}, f"rocprofv3 pass {n + 1} failed: {e!r}"
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return acc, ("collected in this run: rocprofv3 --pmc, one pass each for " + " | ".join(" ".join(c) for c in PMC_PASSES) +
+                 ", over 3 steps of this workload in a child process; averages per launch")
+
+
+def kernel_counters(pmc, name):
+    """Counters of kernel `name` ("k_gather_tile<0>", "k_primary"): the exact kernel, not one whose name merely begins alike."""
+    for k, c in pmc.items():
+        if k == name or k == "pm::" + name or (("<" not in name) and k.split("<")[0] in (name, "pm::" + name)):
+            return c
+    return {}
+
+
+def hbm_traffic(c):
+    """HBM-side bytes per launch: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB; on gfx950 FETCH_SIZE tallies the 128-byte
+    read requests at 64 bytes and is doubled (MI355X_MICROARCH.md, HBM section)."""
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
     return None
 
 
@@ -117,8 +145,9 @@ def main():
     ap.add_argument("--scene", default="default", choices=["default", "spheres10k", "caustics"],
                     help="default = BASELINE config 2 (the bench line); spheres10k / caustics = the synthetic scenes of configs 5 / 4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (roofline.traffic and the instruction counts are then null)")
     ap.add_argument("--cpu-row-stride", type=int, default=1)
-    ap.add_argument("--cpu-cores", type=int, default=0)
+    ap.add_argument("--cpu-cores", type=int, default=0, help="threads of the CPU baseline (default: the cores this process may run on)")
     ap.add_argument("--check", action="store_true", help="compare the CPU sample rows with the GPU pane")
     ap.add_argument("--dump-pane", default="", help="rank 0 writes the final pane (uint32 raw) to this file")
     args = ap.parse_args()
@@ -191,6 +220,7 @@ def main():
     phase = {k: 0.0 for k in ("ms_primary", "ms_secondary", "ms_shadow", "ms_gather_global", "ms_gather_caustic", "ms_gather", "ms_group_global",
                               "ms_group_caustic", "ms_resolve", "ms_total")}
     t_maps = 0.0
+    last_pane = None
     map_ms = [[0.0, 0.0], [0.0, 0.0]]
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -198,7 +228,7 @@ def main():
         frame.build_maps()      # emission + build are left on the library's build streams; render waits for them where it needs them
         t_maps += time.perf_counter() - ta
         st = frame.render()
-        frame.gather_pane()
+        last_pane = frame.gather_pane()
         for k in phase:
             phase[k] += getattr(st, k)
         for kind, m in enumerate(frame.maps):      # device times of the two phases of each map's build (HIP events on its build stream)
@@ -219,48 +249,113 @@ def main():
     else:
         rays = float(tot[1] + tot[2]); gathers = float(tot[3]); sp_local = float(tot[4]); g_ms, c_ms = float(tot[5]), float(tot[6])
 
+    # after the timed region, one more frame that counts the primitive tests of the primary and the shadow pass (same pane,
+    # counting kernels: the intersection roofline needs tests, not rays, once a scene is walked through the sphere grid)
+    tests = None
+    if not use_dist:
+        frame.flags |= ra.PM_FLAG_COUNT_TESTS
+        stc = frame.render()
+        frame.flags &= ~ra.PM_FLAG_COUNT_TESTS
+        tests = {"primary": (stc.tests_primary_sphere, stc.tests_primary_plane), "shadow": (stc.tests_shadow_sphere, stc.tests_shadow_plane)}
+
     out = None
     if rank == 0:
         step_s = dt / args.steps
-        # dominant kernel: the group gather k_gather_tile<map> (one launch per map and step; the two maps run side by side
-        # on two streams).  Units per launch = the shade points that launch answered on this rank.
-        k = 0 if phase["ms_group_global"] >= phase["ms_group_caustic"] else 1
-        dom = ("k_gather_tile<0> (global map)", "k_gather_tile<1> (caustic map)")[k]
-        dom_ms = (phase["ms_group_global"], phase["ms_group_caustic"])[k] / args.steps
-        dom_units = (st.grouped_global, st.grouped_caustic)[k]
-        achieved = ALGO_BYTES_PER_GATHER * dom_units / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic, traffic_note = pmc_traffic(("k_gather_tile<0>", "k_gather_tile<1>")[k])
+        ph = {k: v / args.steps for k, v in phase.items()}
+        pmc, pmc_note = ({}, "skipped (--no-pmc)") if args.no_pmc or use_dist else live_pmc(args)
+        # The dominant kernel of this workload, by device time per step (HIP events on the stream each runs on): the group
+        # gather of either map (one launch per map and step, side by side on two streams), the shadow pass or the primary pass.
+        cand = {"k_gather_tile<0>": ph["ms_group_global"], "k_gather_tile<1>": ph["ms_group_caustic"], "k_shadow_rays": ph["ms_shadow"], "k_primary": ph["ms_primary"]}
+        dom = max(cand, key=cand.get)
+        dom_ms = cand[dom]
+        c = kernel_counters(pmc, dom)
+        valu = c.get("SQ_INSTS_VALU")
+        issue = {"achieved": valu / (dom_ms * 1e-3) / 1e9, "peak": VALU_PEAK_GINSTR_S, "unit": "G wave-instr/s", "frac": valu / (dom_ms * 1e-3) / 1e9 / VALU_PEAK_GINSTR_S,
+                 "valu_instr_per_launch": valu, "salu_instr_per_launch": c.get("SQ_INSTS_SALU"),
+                 "note": "SQ_INSTS_VALU per launch (live PMC pass) / live launch time; peak = 1024 SIMDs x one FP64 wave-instruction per 2.2 ns "
+                         "(tools/microbench/valu_rates.hip); kernels of other streams share the device during that time"} if valu and dom_ms > 0 else None
+        if dom.startswith("k_gather_tile"):
+            k = 0 if dom.endswith("<0>") else 1
+            units = (st.grouped_global, st.grouped_caustic)[k]
+            hbm_ach = ALGO_BYTES_PER_GATHER * units / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+            roof = {"bound": "valu", "kernel": dom + (" (global map)", " (caustic map)")[k],
+                    "achieved": issue["achieved"] if issue else None, "peak": VALU_PEAK_GINSTR_S, "unit": "G wave-instr/s", "frac": issue["frac"] if issue else None,
+                    "traffic": hbm_traffic(c), "traffic_note": pmc_note,
+                    "hbm": {"achieved": hbm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_ach / HBM_PEAK_GBS,
+                            "note": f"SURVEY 8d's figure: algorithmic bytes = {ALGO_BYTES_PER_GATHER} B x {int(units)} gathers answered per launch / launch time; the maps "
+                                    "(64 MB + tables each) stay in L2 / Infinity Cache, so HBM is not what binds this kernel"},
+                    "valu_issue": issue,
+                    "note": f"avg launch {dom_ms:.3f} ms (HIP events on the stream the kernel is launched on; the other map's gather runs beside it on a second stream); "
+                            "the kernel is bound by vector instruction issue (FP64 arithmetic of the selection and of the radiance sum), which is the fraction reported"}
+        else:
+            which = "shadow" if dom == "k_shadow_rays" else "primary"
+            sph, pl = tests[which] if tests else (0, 0)
+            flop = sph * FLOP_PER_SPHERE_TEST + pl * FLOP_PER_PLANE_TEST
+            ach = flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+            roof = {"bound": "valu", "kernel": dom, "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
+                    "traffic": hbm_traffic(c), "traffic_note": pmc_note, "valu_issue": issue,
+                    "note": f"{sph} sphere tests x {FLOP_PER_SPHERE_TEST} + {pl} plane tests x {FLOP_PER_PLANE_TEST} flop (counted on the device by the counting variant of the pass, "
+                            f"same frame) / avg launch {dom_ms:.3f} ms; peak = FP64 vector without FMA contraction"}
+        # the intersection passes against the FP64 peak, whichever kernel dominates (north_star: VALU / occupancy for intersection)
+        inter = None
+        if tests:
+            inter = {}
+            for which, kern, ms in (("primary", "k_primary", ph["ms_primary"]), ("shadow", "k_shadow_rays", ph["ms_shadow"])):
+                sph, pl = tests[which]
+                flop = sph * FLOP_PER_SPHERE_TEST + pl * FLOP_PER_PLANE_TEST
+                kc = kernel_counters(pmc, kern)
+                inter[kern] = {"ms": ms, "sphere_tests": sph, "plane_tests": pl, "tflops": flop / (ms * 1e-3) / 1e12 if ms > 0 else None,
+                               "frac_of_fp64_peak": flop / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if ms > 0 else None,
+                               "valu_instr_per_launch": kc.get("SQ_INSTS_VALU"), "waves_per_launch": kc.get("SQ_WAVES")}
+        per_query = None
+        if pmc:
+            pq = [kernel_counters(pmc, "k_gather<0>"), kernel_counters(pmc, "k_gather<1>")]
+            if all("SQ_INSTS_VALU" in x for x in pq):
+                n_pq = [st.absorb_points - st.grouped_global, st.absorb_points - st.grouped_caustic]
+                tot = sum(2.0 * x["SQ_INSTS_VALU"] for x in pq)    # two launches per map and step: beside the group kernel, and behind it
+                per_query = {"gathers_per_step": int(sum(n_pq)), "valu_instr_per_gather": tot / max(1, sum(n_pq)),
+                             "note": "k_gather<0/1>: SQ_INSTS_VALU per launch (live PMC pass) x 2 launches per map / shade points the group kernels did not answer"}
+        config_tag = " (BASELINE config 2)" if (args.scene, args.width, args.height, args.photons) == ("default", 1440, 1440, 1000000) else ""
         out = {
             "metric": "Mrays/sec + photon-gathers/sec at 1440p, 1/2/4/8 GPUs; frame time (s)",
             "value": rays / step_s / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{WORKLOAD[args.scene]} {args.width}x{args.height}, 1 spp, {args.photons} global + {args.photons} caustic photons, "
-                                   f"k=63, 25 shadow rays, depth<=3{' (BASELINE config 2)' if args.scene == 'default' else ''}; step = emit both maps + build indices + trace/shade + pane on rank 0",
+                                   f"k=63, 25 shadow rays, depth<=3{config_tag}; step = emit both maps + build indices + trace/shade + pane on rank 0",
                        "seed": args.seed, "parallelism": f"rows x{world} (16-row blocks), " + (f"emission attempts x{world} + all-gather" if maps_mode == "allgather" else
                                                                                    "every map emitted on every rank, no exchange" if maps_mode == "replicate" else "one rank"),
                        "maps_autotune_ms_per_step": maps_tune},
             "gathers_per_s": gathers / step_s, "frame_time_s": step_s, "rays_per_frame": rays, "gathers_per_frame": gathers,
-            "phases_ms_rank0": {**{k: v / args.steps for k, v in phase.items()}, "maps_enqueue_host_wall": t_maps / args.steps * 1e3,
+            "phases_ms_rank0": {**ph, "maps_enqueue_host_wall": t_maps / args.steps * 1e3,
                                 "map_global_emit": map_ms[0][0] / args.steps, "map_global_index": map_ms[0][1] / args.steps,
                                 "map_caustic_emit": map_ms[1][0] / args.steps, "map_caustic_index": map_ms[1][1] / args.steps},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                         "note": f"algorithmic bytes = {ALGO_BYTES_PER_GATHER} B x {int(dom_units)} gathers answered per launch; avg launch {dom_ms:.3f} ms "
-                                 f"(HIP events on the stream the kernel is launched on; the other map's gather runs beside it on a second stream)",
-                         "valu_issue": pmc_valu_issue(("k_gather_tile<0>", "k_gather_tile<1>")[k], dom_ms)
-                         if (args.scene, args.width, args.height, args.photons) == ("default", 1440, 1440, 1000000) else None},
+            "roofline": roof, "intersection": inter, "per_query_gather": per_query,
         }
+        if not use_dist:
+            # the reference's boundary hands back a host pane (uint32 *pane of renderScene): the same step with the copy
+            import numpy as _np
+            host = _np.empty((args.height, args.width), dtype=_np.uint32)
+            rp = ctx.params(args.width, args.height, args.seed)
+            th = 0.0
+            for it in range(6):
+                if it == 1:
+                    th = time.perf_counter()           # (the first one allocates the device-side pane)
+                frame.build_maps()
+                ctx.render(frame.maps[0], frame.maps[1], rp, pane=host)
+            out["ms_per_step_host_pane"] = (time.perf_counter() - th) / 5 * 1e3
         if not args.no_cpu_baseline and world == 1:
-            cores = args.cpu_cores or min(os.cpu_count() or 1, 16)
+            avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cores = args.cpu_cores or max(1, min(avail, int(os.environ.get("OMP_NUM_THREADS", avail))))
             cb, cpane = cpu_baseline(frame, args, cores, scene)
+            cb["host_cpus_visible"] = os.cpu_count()
             if args.check:
                 gp = frame.pane.cpu().numpy().view(np.uint32)
                 rows = slice(args.cpu_row_stride // 2, args.height, args.cpu_row_stride)
                 cb["sample_rows_bit_identical_to_gpu"] = bool(np.array_equal(gp[rows], cpane[rows]))
             out["cpu_baseline"] = cb
-        if args.dump_pane:
-            frame.step()[1].cpu().numpy().tofile(args.dump_pane)
+        if args.dump_pane and last_pane is not None:
+            last_pane.cpu().numpy().tofile(args.dump_pane)      # the pane the last timed step gathered on rank 0
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     frame.close()

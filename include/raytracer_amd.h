@@ -61,6 +61,8 @@ typedef struct pm_map pm_map;   /* replaces kdnode* (src/PhotonMap.h:15-20) */
 #define PM_FLAG_NO_GLOBAL 1     /* skip the global-map gather (src/Raytrace.cpp:96-131) */
 #define PM_FLAG_NO_CAUSTIC 2    /* skip the caustic-map gather (:135-171) */
 #define PM_FLAG_NO_DIRECT 4     /* zero the shadow-ray direct term (:174-212) */
+#define PM_FLAG_COUNT_TESTS 8   /* diagnostics: the primary and the shadow pass count the SphereObject / PlaneObject::intersect calls they
+                                 * make (pm_stats.tests_*); same pane, slower kernels -- never the frame that is timed */
 
 #define PM_K 63                 /* PHOTONS_IN_ESTIMATE, src/Raytrace.cpp:16,21 (heap only defined for 63, PhotonMap.cpp:174) */
 #define PM_ROW_BLOCK 16         /* rows per interleaved row block when a frame is split over ranks */
@@ -89,6 +91,9 @@ typedef struct pm_stats {
      * answers the rest */
     float ms_group_global, ms_group_caustic;
     uint32_t grouped_global, grouped_caustic;
+    /* with PM_FLAG_COUNT_TESTS: primitive intersection tests executed by the primary closest-hit pass and by the shadow any-hit pass
+     * (a scene of 64 spheres or more is walked through the sphere grid: far fewer than rays x primitives) */
+    uint64_t tests_primary_sphere, tests_primary_plane, tests_shadow_sphere, tests_shadow_plane;
 } pm_stats;
 
 /* scheduler::startWorkers(int), src/JobSystem.cpp:76-86 (called at src/Main.cpp:34): `device` takes the place of `cores`.

@@ -6,7 +6,7 @@ orchestration incl. the multi-GPU split).  There is no CPU fallback: importing w
 but every compute call needs the built library and a gfx950 device and fails loudly otherwise.
 """
 from .capi import (  # noqa: F401
-    PM_MAP_GLOBAL, PM_MAP_CAUSTIC, PM_FLAG_NO_GLOBAL, PM_FLAG_NO_CAUSTIC, PM_FLAG_NO_DIRECT,
+    PM_MAP_GLOBAL, PM_MAP_CAUSTIC, PM_FLAG_NO_GLOBAL, PM_FLAG_NO_CAUSTIC, PM_FLAG_NO_DIRECT, PM_FLAG_COUNT_TESTS,
     PMError, Context, PhotonMap, RenderParams, Stats, default_scene, prim_dtype, photon_dtype, load_library,
 )
 from .scenes import many_spheres_scene, caustics_scene  # noqa: F401,E402

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 PM_MAP_GLOBAL, PM_MAP_CAUSTIC = 0, 1
-PM_FLAG_NO_GLOBAL, PM_FLAG_NO_CAUSTIC, PM_FLAG_NO_DIRECT = 1, 2, 4
+PM_FLAG_NO_GLOBAL, PM_FLAG_NO_CAUSTIC, PM_FLAG_NO_DIRECT, PM_FLAG_COUNT_TESTS = 1, 2, 4, 8
 PM_K = 63
 PM_ROW_BLOCK = 16
 PM_EMIT_STATIC_MAX_ATTEMPTS = 131072
@@ -41,7 +41,9 @@ class Stats(C.Structure):
                 ("ms_primary", C.c_float), ("ms_secondary", C.c_float), ("ms_shadow", C.c_float),
                 ("ms_gather_global", C.c_float), ("ms_gather_caustic", C.c_float), ("ms_resolve", C.c_float),
                 ("ms_total", C.c_float), ("ms_gather", C.c_float), ("ms_group_global", C.c_float), ("ms_group_caustic", C.c_float),
-                ("grouped_global", C.c_uint32), ("grouped_caustic", C.c_uint32)]
+                ("grouped_global", C.c_uint32), ("grouped_caustic", C.c_uint32),
+                ("tests_primary_sphere", C.c_uint64), ("tests_primary_plane", C.c_uint64),
+                ("tests_shadow_sphere", C.c_uint64), ("tests_shadow_plane", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -1032,14 +1032,17 @@ static int enqueue_frame(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
 
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
     HIPCHK(hipMemsetAsync(d_ctr, 0, sizeof(Counters), ctx->stream));
-    LAUNCH_SCENE(k_primary, grid_px, block, ctx, fp, d_pane, d_ctr, q, ctx->clist.as<uint32_t>(), ctx->groups.as<uint2>());
+    const bool count_tests = (rp->flags & PM_FLAG_COUNT_TESTS) != 0;
+    if (count_tests) LAUNCH_SCENE(k_primary_count, grid_px, block, ctx, fp, d_pane, d_ctr, q, ctx->clist.as<uint32_t>(), ctx->groups.as<uint2>());
+    else LAUNCH_SCENE(k_primary, grid_px, block, ctx, fp, d_pane, d_ctr, q, ctx->clist.as<uint32_t>(), ctx->groups.as<uint2>());
     hipLaunchKernelGGL(k_mark_primary, dim3(1), dim3(64), 0, ctx->stream, d_ctr, q.cap);
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
     LAUNCH_SCENE(k_secondary, dim3(std::min<unsigned>((c_cap + 255) / 256, 4096u)), block, ctx, fp, d_ctr, q, ctx->clist.as<uint32_t>(), c_cap, tab);
     hipLaunchKernelGGL(k_mark_secondary, dim3(1), dim3(64), 0, ctx->stream, d_ctr, q.cap, b_cap);
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
     // one lane per shadow ray; or (A/B switch) one lane per shade point with its 25 rays in sequence
-    if (ctx->shadow_per_ray) LAUNCH_SCENE(k_shadow_rays, dim3(std::min<unsigned>((q.cap + 9) / 10, 4 * cus8)), block, ctx, fp, q, d_ctr);
+    if (count_tests) LAUNCH_SCENE(k_shadow_rays_count, dim3(std::min<unsigned>((q.cap + 9) / 10, 4 * cus8)), block, ctx, fp, q, d_ctr);
+    else if (ctx->shadow_per_ray) LAUNCH_SCENE(k_shadow_rays, dim3(std::min<unsigned>((q.cap + 9) / 10, 4 * cus8)), block, ctx, fp, q, d_ctr);
     else LAUNCH_SCENE(k_shadow, dim3(std::min<unsigned>((q.cap + 255) / 256, 2 * cus8)), block, ctx, fp, q, d_ctr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
@@ -1224,7 +1227,10 @@ static int render_impl(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_
         }
         if (!again) break;
     }
-    if (!pane_on_device) {
+    if (!pane_on_device && rp->world == 1) {
+        HIPCHK(hipMemcpyAsync(pane, d_pane, (size_t)W * H * 4, hipMemcpyDeviceToHost, ctx->stream));   // one rank owns every row: one copy
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    } else if (!pane_on_device) {
         for (int b = rp->rank; b < nblk; b += rp->world) {
             size_t y0 = (size_t)b * PM_ROW_BLOCK, y1 = std::min<size_t>(y0 + PM_ROW_BLOCK, (size_t)H);
             HIPCHK(hipMemcpyAsync(pane + y0 * W, d_pane + y0 * W, (y1 - y0) * W * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1267,6 +1273,8 @@ static int render_impl(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_
         stats->gathers = (uint64_t)n_gathers * n_sp;
         stats->absorb_points = n_sp;
         stats->complex_pixels = n_complex;
+        stats->tests_primary_sphere = hc.tests[0]; stats->tests_primary_plane = hc.tests[1];
+        stats->tests_shadow_sphere = hc.tests[2]; stats->tests_shadow_plane = hc.tests[3];
         (void)hipEventElapsedTime(&stats->ms_primary, ctx->ev[0], ctx->ev[1]);
         (void)hipEventElapsedTime(&stats->ms_secondary, ctx->ev[1], ctx->ev[2]);
         (void)hipEventElapsedTime(&stats->ms_shadow, ctx->ev[2], ctx->ev[3]);

@@ -195,9 +195,13 @@ __device__ inline void plane_normal(const SceneView &s, int kind, int i, V3 &nrm
     else if (kind == PK_PLANE_Y) nrm.y = s.f(G_Y, i) < 0 ? 1 : -1;
     else nrm.z = s.f(G_Z, i) < 0 ? 1 : -1;
 }
-__device__ inline bool prim_hit(const SceneView &s, int i, const V3 &o, const V3 &d, double dt, V3 &res) {
+// primitive tests a lane has made (the bench's intersection roofline counts them: 22 flop per sphere test, 6 per plane test,
+// SURVEY section 8d); only the counting variants of the kernels pass one, everywhere else the pointer is a compile-time null
+struct TestCount { uint32_t spheres, planes; };
+__device__ inline bool prim_hit(const SceneView &s, int i, const V3 &o, const V3 &d, double dt, V3 &res, TestCount *tc = nullptr) {
     int kind = s.kind[i];
-    if (kind == PK_SPHERE) return sphere_hit(s, i, o, d, dt, res);
+    if (kind == PK_SPHERE) { if (tc) tc->spheres++; return sphere_hit(s, i, o, d, dt, res); }
+    if (tc) tc->planes++;
     return plane_hit(s, kind, i, o, d, res);
 }
 __device__ inline void prim_normal(const SceneView &s, int i, double dt, const V3 &res, V3 &nrm) {
@@ -260,14 +264,14 @@ __device__ inline void grid_walk(const SceneGrid &G, const V3 &o, const V3 &d, F
 // Scene::intersect, src/Scene.cpp:25-47: closest hit by squared distance of the reconstructed
 // hit point, strict '<' so the lowest index wins ties; returns object id or -1
 template <int MODE>
-__device__ inline int scene_intersect(const SceneView &s, const V3 &src, const V3 &dir, int exclude, double dt, V3 &fres, V3 &fnrm) {
+__device__ inline int scene_intersect(const SceneView &s, const V3 &src, const V3 &dir, int exclude, double dt, V3 &fres, V3 &fnrm, TestCount *tc = nullptr) {
     double nearest = 1024 * 1024;
     int nearest_obj = -1;
     V3 res = {0, 0, 0};
     if (MODE != SCENE_GRID) {
         for (int i = 0; i < s.n; i++) {
             if (i == exclude) continue;
-            if (prim_hit(s, i, src, dir, dt, res)) {
+            if (prim_hit(s, i, src, dir, dt, res, tc)) {
                 double dist = (res.x - src.x) * (res.x - src.x);
                 dist += (res.y - src.y) * (res.y - src.y);
                 dist += (res.z - src.z) * (res.z - src.z);
@@ -281,7 +285,7 @@ __device__ inline int scene_intersect(const SceneView &s, const V3 &src, const V
     // smaller distance, or the same distance and a lower index -- what the strict '<' of the index-order scan yields.
     auto candidate = [&](int i) {
         if (i == exclude) return;
-        if (prim_hit(s, i, src, dir, dt, res)) {
+        if (prim_hit(s, i, src, dir, dt, res, tc)) {
             double dist = (res.x - src.x) * (res.x - src.x);
             dist += (res.y - src.y) * (res.y - src.y);
             dist += (res.z - src.z) * (res.z - src.z);
@@ -301,6 +305,7 @@ __device__ inline int scene_intersect(const SceneView &s, const V3 &src, const V
             const double *P = G.packed + (size_t)r * 8;
             const int i = (int)__double_as_longlong(P[7]);
             if (i == exclude) continue;
+            if (tc) tc->spheres++;
             if (sphere_hit_packed(P, src, dir, dt, res)) {
                 double dist = (res.x - src.x) * (res.x - src.x);
                 dist += (res.y - src.y) * (res.y - src.y);
@@ -318,11 +323,11 @@ __device__ inline int scene_intersect(const SceneView &s, const V3 &src, const V
 // distance from p is not beyond max_dist (the first such primitive in index order ends the reference's loop; which one
 // it is does not matter).
 template <int MODE>
-__device__ inline bool shadow_blocked(const SceneView &s, const V3 &p, const V3 &ray, double dt, int obj, double max_dist) {
+__device__ inline bool shadow_blocked(const SceneView &s, const V3 &p, const V3 &ray, double dt, int obj, double max_dist, TestCount *tc = nullptr) {
     V3 result = {0, 0, 0};
     auto blocks = [&](int k) {
         if (k == obj) return false;
-        if (!prim_hit(s, k, p, ray, dt, result)) return false;
+        if (!prim_hit(s, k, p, ray, dt, result, tc)) return false;
         double ds = (p.x - result.x) * (p.x - result.x) + (p.y - result.y) * (p.y - result.y) + (p.z - result.z) * (p.z - result.z);
         return !(ds > max_dist);
     };
@@ -340,6 +345,7 @@ __device__ inline bool shadow_blocked(const SceneView &s, const V3 &p, const V3 
         for (uint32_t r = b; r < e; r++) {
             const double *P = G.packed + (size_t)r * 8;
             if ((int)__double_as_longlong(P[7]) == obj) continue;
+            if (tc) tc->spheres++;
             if (!sphere_hit_packed(P, p, ray, dt, result)) continue;
             double ds = (p.x - result.x) * (p.x - result.x) + (p.y - result.y) * (p.y - result.y) + (p.z - result.z) * (p.z - result.z);
             if (!(ds > max_dist)) { hit = true; return false; }

@@ -29,7 +29,7 @@ struct FrameParams {
     int rank, world;
 };
 
-struct Counters { uint32_t n_sp, n_complex, n_secondary, n_groups, n_left[2][4], pad, n_sgroups, n_early, n_pieces, overflow, n_sp0, n_bounced, done_primary, done_secondary; uint32_t why[8]; unsigned long long tphase[8]; uint32_t ghist[2][32]; };   // n_left[k][p]: shade points that part p of map k's group launches left to the per-query gather
+struct Counters { uint32_t n_sp, n_complex, n_secondary, n_groups, n_left[2][4], pad, n_sgroups, n_early, n_pieces, overflow, n_sp0, n_bounced, done_primary, done_secondary; unsigned long long tests[4]; uint32_t why[8]; unsigned long long tphase[8]; uint32_t ghist[2][32]; };   // n_left[k][p]: shade points that part p of map k's group launches left to the per-query gather
 
 // The frame's counts live on the device: nothing of a frame waits for the host.  n_sp0 = shade points of primary hits (slots
 // 0 .. n_sp0, grouped by pixel tile), written by k_mark_primary behind k_primary; n_bounced = shade points of bounced pixels
@@ -94,9 +94,16 @@ __device__ inline bool tile_pixel(const FrameParams &fp, int &x, int &y) {
     return x < fp.width && y < fp.height;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_primary(SceneView gs, FrameParams fp, uint32_t *pane, Counters *ctr, SPQueue q, uint32_t *complex_list, uint2 *groups) {
+// sum of a lane counter over the wave, added to a device counter by one lane (the counting variants of the kernels)
+__device__ inline void wave_add_count(unsigned long long *to, uint32_t mine) {
+    uint32_t v = mine;
+    for (int s = 1; s < 64; s <<= 1) v += (uint32_t)__shfl_xor((int)v, s);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(to, (unsigned long long)v);
+}
+template <int MODE, bool COUNT>
+__device__ inline void primary_body(const SceneView &gs, const FrameParams &fp, uint32_t *pane, Counters *ctr, const SPQueue &q, uint32_t *complex_list, uint2 *groups) {
     extern __shared__ __align__(16) unsigned char smem[];
+    TestCount tc = {0u, 0u};
     SceneView sv = gs;
     if (MODE == SCENE_LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
     int x, y;
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(256) void k_primary(SceneView gs, FrameParams fp, u
         pixel = (uint32_t)x + (uint32_t)y * (uint32_t)fp.width;
         V3 ray = primary_ray(fp.width, fp.height, fp.cam, fp.K, pixel, x, y);
         double dt = draw(item_key(fp.K, (uint64_t)pixel * 32u + 1u), 0);   // traceRay's own draw, src/Raytrace.cpp:39
-        obj = scene_intersect<MODE>(sv, fp.cam, ray, -1, dt, res, nrm);
+        obj = scene_intersect<MODE>(sv, fp.cam, ray, -1, dt, res, nrm, COUNT ? &tc : nullptr);
         if (obj < 0) pane[pixel] = 0xFF000000u;
         else if (is_light_patch(res)) pane[pixel] = light_colour(fp.light);
         else if (sv.f(G_TRANSMISSION, obj) > 0 || sv.f(G_SPECULAR, obj) > 0) emit_cx = true;
@@ -137,6 +144,16 @@ __global__ __launch_bounds__(256) void k_primary(SceneView gs, FrameParams fp, u
         base = __shfl(base, leader);
         if (emit_cx) complex_list[base + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL))] = pixel;
     }
+    if (COUNT) { wave_add_count(&ctr->tests[0], tc.spheres); wave_add_count(&ctr->tests[1], tc.planes); }
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k_primary(SceneView gs, FrameParams fp, uint32_t *pane, Counters *ctr, SPQueue q, uint32_t *complex_list, uint2 *groups) {
+    primary_body<MODE, false>(gs, fp, pane, ctr, q, complex_list, groups);
+}
+// the same pass counting the primitive tests it makes (PM_FLAG_COUNT_TESTS: the bench's intersection roofline; never the timed frame)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_primary_count(SceneView gs, FrameParams fp, uint32_t *pane, Counters *ctr, SPQueue q, uint32_t *complex_list, uint2 *groups) {
+    primary_body<MODE, true>(gs, fp, pane, ctr, q, complex_list, groups);
 }
 // the counts of the pass that just ended, for the kernels behind it (one thread)
 __global__ void k_mark_primary(Counters *ctr, uint32_t cap) {
@@ -384,10 +401,11 @@ __global__ __launch_bounds__(256) void k_sp_classify(SPQueue q, const uint32_t *
 // The work is cut 25 times finer, so every SIMD stays busy until the end and the pass shares the device better with the
 // map builds beside it (default scene: the pass itself 0.24 -> 0.28 ms, the step 3.10 -> 3.05 ms; 10 000 spheres, where a
 // ray ends at its first blocker or walks cells all the way to the light: step 13.3 -> 11.8 ms).
-template <int MODE>
-__global__ __launch_bounds__(256) void k_shadow_rays(SceneView gs, FrameParams fp, SPQueue q, const Counters *ctr) {
+template <int MODE, bool COUNT>
+__device__ inline void shadow_rays_body(const SceneView &gs, const FrameParams &fp, const SPQueue &q, Counters *ctr) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int blocked[10];
+    TestCount tc = {0u, 0u};
     SceneView sv = gs;
     if (MODE == SCENE_LDS) { sv = stage_scene(gs, smem); }
     const uint32_t n_sp = sp_total(ctr, q.cap);      // launched for the queue's capacity: blocks take groups of 10 shade points in turn
@@ -409,7 +427,7 @@ __global__ __launch_bounds__(256) void k_shadow_rays(SceneView gs, FrameParams f
             const double max_dist = shadow_ray.x * shadow_ray.x + shadow_ray.y * shadow_ray.y + shadow_ray.z * shadow_ray.z;
             normalize(shadow_ray);
             const double dt = draw(IK, 3 + 3 * i);
-            if (shadow_blocked<MODE>(sv, p, shadow_ray, dt, obj, max_dist)) atomicAdd(&blocked[local], 1);
+            if (shadow_blocked<MODE>(sv, p, shadow_ray, dt, obj, max_dist, COUNT ? &tc : nullptr)) atomicAdd(&blocked[local], 1);
         }
         __syncthreads();
         if (live && i == 24u) {        // the direct term uses the direction of the LAST shadow ray, src/Raytrace.cpp:207-212
@@ -425,7 +443,12 @@ __global__ __launch_bounds__(256) void k_shadow_rays(SceneView gs, FrameParams f
         }
         __syncthreads();               // `blocked` is cleared for the next group
     }
+    if (COUNT) { wave_add_count(&ctr->tests[2], tc.spheres); wave_add_count(&ctr->tests[3], tc.planes); }
 }
+template <int MODE>
+__global__ __launch_bounds__(256) void k_shadow_rays(SceneView gs, FrameParams fp, SPQueue q, Counters *ctr) { shadow_rays_body<MODE, false>(gs, fp, q, ctr); }
+template <int MODE>
+__global__ __launch_bounds__(256) void k_shadow_rays_count(SceneView gs, FrameParams fp, SPQueue q, Counters *ctr) { shadow_rays_body<MODE, true>(gs, fp, q, ctr); }
 
 // One draw from a work counter per wave.  Out of line on purpose: inlined into the scheduling loop, the
 // lane-0 branch was threaded into the loop's control flow and lanes 1..63 were sent round the loop on their own.

@@ -14,8 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("scene,stride", [("default", 4), ("caustics", 4), ("spheres10k", 48)])
 def test_full_size_frame_rows_equal_the_oracle(scene, stride):
+    # the default scene also goes through the live counter passes (rocprofv3 child processes); the others skip them to save time
+    extra = [] if scene == "default" else ["--no-pmc"]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--scene", scene, "--check",
-                        "--cpu-row-stride", str(stride)], capture_output=True, text=True, timeout=900)
+                        "--cpu-row-stride", str(stride)] + extra, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     cb = j["cpu_baseline"]
@@ -23,3 +25,15 @@ def test_full_size_frame_rows_equal_the_oracle(scene, stride):
     assert f"{len(range(stride // 2, 1440, stride))} rows" in cb["sample"]
     assert j["rays_per_frame"] > 10e6 and j["gathers_per_frame"] > 1e6 and j["value"] > 0
     assert "1440x1440" in j["config"]["workload"] and "1000000 global" in j["config"]["workload"]
+    roof = j["roofline"]
+    assert roof["bound"] == "valu" and roof["kernel"]
+    # the scene decides which kernel dominates: the group gather on the two Cornell scenes, the shadow pass through 10 000 spheres
+    assert ("k_shadow_rays" in roof["kernel"]) == (scene == "spheres10k"), roof["kernel"]
+    inter = j["intersection"]
+    assert inter["k_primary"]["plane_tests"] == 5 * 1440 * 1440 and inter["k_shadow_rays"]["sphere_tests"] > 0
+    if scene == "default":
+        assert inter["k_primary"]["sphere_tests"] == 2 * 1440 * 1440          # the linear scan: every ray tests every primitive
+        assert roof["traffic"] and roof["traffic"] > 0 and 0 < roof["frac"] < 1, roof   # counters collected in this very run
+        assert j["per_query_gather"]["valu_instr_per_gather"] > 0
+    else:
+        assert roof["traffic"] is None

@@ -180,7 +180,7 @@ def test_bench_collective_path_on_one_rank(tmp_path, orc, maps):
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
-    assert j["n_gpus"] == 1 and j["value"] > 0 and j["roofline"]["achieved"] > 0
+    assert j["n_gpus"] == 1 and j["value"] > 0 and j["roofline"]["kernel"] and j["roofline"]["traffic"] is None   # (no counter passes beside a process group)
     tune = j["config"]["maps_autotune_ms_per_step"]
     assert (set(tune) == {"allgather", "replicate"}) if maps == "auto" else tune is None
     pane = np.fromfile(out, dtype=np.uint32).reshape(200, 320)

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/insts
 rm -rf $out && mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 200 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES -d $out/p -o pmc -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline $* > $out/run.log 2>&1 || { tail -5 $out/run.log; exit 1; }
+timeout -s KILL 200 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES -d $out/p -o pmc -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc $* > $out/run.log 2>&1 || { tail -5 $out/run.log; exit 1; }
 python3 $R/tools/pmc_summary.py $out/p > $out/insts.json
 python3 - <<PY
 import json

@@ -9,7 +9,7 @@ R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline $*"
+CMD="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pmc $*"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o tr -- $CMD > $out/trace.log 2>&1 || { echo "trace run failed"; tail -5 $out/trace.log; exit 1; }
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \

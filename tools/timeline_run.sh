@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 200 rocprofv3 --kernel-trace --output-format csv -d $out/trace -o tr -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline $* > $out/trace.log 2>&1 || { tail -5 $out/trace.log; exit 1; }
+timeout -s KILL 200 rocprofv3 --kernel-trace --output-format csv -d $out/trace -o tr -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-pmc $* > $out/trace.log 2>&1 || { tail -5 $out/trace.log; exit 1; }
 python3 $R/tools/timeline.py $out/trace/tr_kernel_trace.csv $floor > $out/timeline.txt
 rm -rf $out/trace
 cat $out/timeline.txt
