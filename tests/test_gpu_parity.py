@@ -189,3 +189,27 @@ def test_bench_collective_path_on_one_rank(tmp_path, orc, maps):
     want, _ = orc.render(scene, g, c, orc.params(320, 200, 77), nthreads=8)
     assert np.array_equal(pane, want)
     g.close(); c.close()
+
+
+def test_bench_two_ranks_over_rccl(tmp_path, orc):
+    """The real N > 1 path (emission split by attempt range, RCCL all-gather of the shards, row blocks gathered to rank 0):
+    bench.py under torch.distributed.run with two ranks, its assembled pane against the oracle's.  Needs two GPUs."""
+    import os, subprocess, sys, json
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: the two-rank RCCL path needs two")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for maps in ("allgather", "replicate"):
+        out = tmp_path / f"pane_{maps}.bin"
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+                            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--width", "320", "--height", "200", "--photons", "20000",
+                            "--seed", "77", "--no-cpu-baseline", "--maps", maps, "--dump-pane", str(out)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert j["n_gpus"] == 2 and j["value"] > 0
+        pane = np.fromfile(out, dtype=np.uint32).reshape(200, 320)
+        scene = orc.default_scene()
+        g, c = orc.Map(orc.emit(scene, 0, 77, 20000)[0]), orc.Map(orc.emit(scene, 1, 77, 20000)[0])
+        want, _ = orc.render(scene, g, c, orc.params(320, 200, 77), nthreads=8)
+        assert np.array_equal(pane, want), maps
+        g.close(); c.close()
