@@ -309,12 +309,14 @@ def main():
                                "valu_instr_per_launch": kc.get("SQ_INSTS_VALU"), "waves_per_launch": kc.get("SQ_WAVES")}
         per_query = None
         if pmc:
-            pq = [kernel_counters(pmc, "k_gather<0>"), kernel_counters(pmc, "k_gather<1>")]
+            # the per-query kernel the frame used: two shade points per wave (k_gather_pair), or one (k_gather, PM_PAIR=0)
+            pq_name = "k_gather_pair" if kernel_counters(pmc, "k_gather_pair<0>") else "k_gather"
+            pq = [kernel_counters(pmc, pq_name + "<0>"), kernel_counters(pmc, pq_name + "<1>")]
             if all("SQ_INSTS_VALU" in x for x in pq):
                 n_pq = [st.absorb_points - st.grouped_global, st.absorb_points - st.grouped_caustic]
                 tot = sum(2.0 * x["SQ_INSTS_VALU"] for x in pq)    # two launches per map and step: beside the group kernel, and behind it
                 per_query = {"gathers_per_step": int(sum(n_pq)), "valu_instr_per_gather": tot / max(1, sum(n_pq)),
-                             "note": "k_gather<0/1>: SQ_INSTS_VALU per launch (live PMC pass) x 2 launches per map / shade points the group kernels did not answer"}
+                             "kernel": pq_name + "<0/1>", "note": "SQ_INSTS_VALU per launch (live PMC pass) x 2 launches per map / shade points the group kernels did not answer"}
         config_tag = " (BASELINE config 2)" if (args.scene, args.width, args.height, args.photons) == ("default", 1440, 1440, 1000000) else ""
         out = {
             "metric": "Mrays/sec + photon-gathers/sec at 1440p, 1/2/4/8 GPUs; frame time (s)",

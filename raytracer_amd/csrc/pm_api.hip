@@ -99,7 +99,8 @@ struct pm_ctx {
     int sp_min_run = 16;
     double sp_est = 1.0;       // a piece is grouped when its expected candidate set is within this many times PM_TILE_EST_MAX (PM_SP_EST)
     bool group_bounced = true; // PM_GROUP_BOUNCED=0: the bounced pixels' shade points stay with the per-query kernel (A/B switch)
-    int tile_blocks = 0, query_blocks = 0;   // resident blocks of the two gather kernels on this device
+    int tile_blocks = 0, query_blocks = 0, pair_blocks = 0;   // resident blocks of the gather kernels on this device
+    bool use_pairs = true;     // PM_PAIR=0: the per-query gather takes one shade point per wave (k_gather) instead of two (k_gather_pair)
     uint32_t sp_cap = 0, c_cap = 0, b_cap = 0;   // slots of the shade point queue; node tables (bounced pixels); bounced pixels' shade points the spatial sort takes
     bool yield_known[2] = {false, false};        // a map of this scene and kind has reported what an emission attempt yields
     Counters *h_ctr = nullptr;   // pinned
@@ -982,12 +983,15 @@ static int gather_blocks(pm_ctx *ctx) {
     if (ctx->tile_blocks) return PM_OK;
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
-    int per_cu_t = 0, per_cu_q = 0;
+    int per_cu_t = 0, per_cu_q = 0, per_cu_p = 0;
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_t, k_gather_tile<0>, 64, 0));
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_q, k_gather<0>, 256, 0));
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_p, k_gather_pair<0>, 256, 0));
     int cus = std::max(8, prop.multiProcessorCount);
     ctx->tile_blocks = std::max(8, std::max(1, per_cu_t) * cus / 8 * 8);
     ctx->query_blocks = std::max(8, std::max(1, per_cu_q) * cus / 8 * 8);
+    ctx->pair_blocks = std::max(8, std::max(1, per_cu_p) * cus / 8 * 8);
+    if (const char *v = getenv("PM_PAIR")) ctx->use_pairs = v[0] != '0';
     const char *e = getenv("PM_GATHER_TILE");
     ctx->use_tiles = !(e && e[0] == '0');
     const char *eb = getenv("PM_GROUP_BOUNCED");
@@ -1095,7 +1099,10 @@ static int enqueue_frame(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
     const uint32_t nparts = use_tiles ? (uint32_t)ctx->tile_parts : 1u;
     auto per_query = [&](int kind, pm_map *map, hipStream_t on, const uint32_t *list, const uint32_t *count, int mode) {
         uint32_t *sc = sched + (size_t)(n_sched++) * SCHED_WORDS;
-        if (kind == 0) hipLaunchKernelGGL(k_gather<0>, dim3(ctx->query_blocks), block, 0, on, map->view, q, list, count, d_ctr, mode, sc);
+        if (ctx->use_pairs) {
+            if (kind == 0) hipLaunchKernelGGL(k_gather_pair<0>, dim3(ctx->pair_blocks), block, 0, on, map->view, q, list, count, d_ctr, mode, sc);
+            else hipLaunchKernelGGL(k_gather_pair<1>, dim3(ctx->pair_blocks), block, 0, on, map->view, q, list, count, d_ctr, mode, sc);
+        } else if (kind == 0) hipLaunchKernelGGL(k_gather<0>, dim3(ctx->query_blocks), block, 0, on, map->view, q, list, count, d_ctr, mode, sc);
         else hipLaunchKernelGGL(k_gather<1>, dim3(ctx->query_blocks), block, 0, on, map->view, q, list, count, d_ctr, mode, sc);
     };
     // first the waits for the maps, and on the third stream what needs no group kernel before it

@@ -17,6 +17,7 @@
 #include "pm_knn.h"
 #include "pm_grid.h"
 #include "pm_tile.h"
+#include "pm_pair.h"
 
 namespace pm {
 
@@ -533,6 +534,52 @@ __global__ __launch_bounds__(256) void k_gather(MapView m_in, SPQueue q, const u
         o[0] = (uint32_t)wt0; o[1] = (uint32_t)wt1; o[2] = wq; o[3] = wd.xcd;
     }
 #endif
+}
+
+// The same items, two per wave (pm_pair.h): each half-wave answers one shade point with a block query; a shade point the block
+// query cannot answer (far from the photons, a dense cluster next door) is then taken by the whole wave with the octree walk,
+// right here.  The kernel the frame uses (PM_PAIR=0: k_gather, for A/B runs).
+template <int KIND>
+__global__ __launch_bounds__(256) void k_gather_pair(MapView m_in, SPQueue q, const uint32_t *left, const uint32_t *n_left, const Counters *ctr, int sec_mode,
+                                                     uint32_t *sched) {
+    MapView m = m_in;
+    load_grid(m);
+    union PairOrKnn { PairBuf pair; KnnBuf knn; };
+    __shared__ PairOrKnn bufs[4];
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    PairOrKnn *buf = &bufs[wave_in_block];
+    const int lane = threadIdx.x & 63, half = lane >> 5;
+    double *out = KIND == 0 ? q.rad_g : q.rad_c;
+    const uint32_t sec_lo = sec_mode == 1 ? ctr->n_sp0 : 0u;
+    const uint32_t sec_n = sec_mode == 1 ? ctr->n_bounced : (sec_mode == 2 ? sp_total(ctr, q.cap) : 0u);
+    const uint32_t nl = *n_left, n_items = nl + sec_n;
+    WorkDraw wd;
+    uint32_t i0, i1;
+    while (wd.next(sched, n_items, 2u, i0, i1)) {
+        const bool have = i0 + (uint32_t)half < i1;
+        const uint32_t i = have ? i0 + (uint32_t)half : i0;
+        const uint32_t s = i < nl ? left[i] : sec_lo + (i - nl);
+        const V3 p = {q.geo[0 * (size_t)q.cap + s], q.geo[1 * (size_t)q.cap + s], q.geo[2 * (size_t)q.cap + s]};
+        const V3 nrm = {q.geo[3 * (size_t)q.cap + s], q.geo[4 * (size_t)q.cap + s], q.geo[5 * (size_t)q.cap + s]};
+        double R, G, B;
+        const bool ok = pair_gather<KIND>(&buf->pair, m, p, nrm, have, R, G, B);
+        if (ok && (lane & 31) == 0) { out[0 * (size_t)q.cap + s] = R; out[1 * (size_t)q.cap + s] = G; out[2 * (size_t)q.cap + s] = B; }
+        // what a half could not answer: the whole wave, with the walk
+        unsigned long long todo = __ballot(have && !ok && (lane & 31) == 0);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const uint32_t s2 = (uint32_t)__shfl((int)s, src);
+            const V3 p2 = {__shfl(p.x, src), __shfl(p.y, src), __shfl(p.z, src)}, n2 = {__shfl(nrm.x, src), __shfl(nrm.y, src), __shfl(nrm.z, src)};
+            KnnCarry carry;
+            carry.full = false;
+            double R2, G2, B2;
+            wave_lds_fence();
+            knn_gather<KIND>(&buf->knn, m, p2, n2, R2, G2, B2, carry);
+            if (lane == 0) { out[0 * (size_t)q.cap + s2] = R2; out[1 * (size_t)q.cap + s2] = G2; out[2 * (size_t)q.cap + s2] = B2; }
+            wave_lds_fence();
+        }
+    }
 }
 
 // One wave per GROUP of shade points (pm_tile.h): the shade points of one 8x8 pixel tile, one per lane.  A group that
