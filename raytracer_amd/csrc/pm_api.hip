@@ -86,6 +86,7 @@ struct pm_ctx {
     int nprims = 0, stride = 0;
     double yield[2] = {0.60, 0.36};   // stored photons per emission attempt (global, caustic): the reference scene's to begin with, then
                                       // what the last map of this scene showed (sizes the one emission range a map is made from)
+    bool shadow_queue = true;         // sphere grid: the rays of a wave share a queue of tests (PM_SHADOW_QUEUE=0: every ray tests on its own, for A/B runs)
     bool shadow_per_ray = true;       // one lane per shadow ray rather than per shade point (PM_SHADOW_PER_RAY=0: the latter, for A/B runs)
     int scene_mode = SCENE_LDS;   // SCENE_LDS: staged per block; SCENE_GLOBAL: read in place; SCENE_GRID: in place, through the sphere grid
     size_t scene_b = 0;
@@ -382,6 +383,7 @@ extern "C" int pm_scene_upload(pm_ctx *ctx, const pm_prim *prims, int32_t n) {
                                         hg.refs.size(), nspheres, hg.loose.size());
     }
     if (const char *e = getenv("PM_SHADOW_PER_RAY")) ctx->shadow_per_ray = e[0] != '0';
+    if (const char *e = getenv("PM_SHADOW_QUEUE")) ctx->shadow_queue = e[0] != '0';
     return PM_OK;
 }
 
@@ -1045,8 +1047,11 @@ static int enqueue_frame(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
     hipLaunchKernelGGL(k_mark_secondary, dim3(1), dim3(64), 0, ctx->stream, d_ctr, q.cap, b_cap);
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
     // one lane per shadow ray; or (A/B switch) one lane per shade point with its 25 rays in sequence
-    if (count_tests) LAUNCH_SCENE(k_shadow_rays_count, dim3(std::min<unsigned>((q.cap + 9) / 10, 4 * cus8)), block, ctx, fp, q, d_ctr);
-    else if (ctx->shadow_per_ray) LAUNCH_SCENE(k_shadow_rays, dim3(std::min<unsigned>((q.cap + 9) / 10, 4 * cus8)), block, ctx, fp, q, d_ctr);
+    const dim3 grid_sh(std::min<unsigned>((q.cap + 9) / 10, 4 * cus8));
+    if (count_tests && ctx->shadow_queue) LAUNCH_SCENE(k_shadow_rays_count, grid_sh, block, ctx, fp, q, d_ctr);
+    else if (count_tests) LAUNCH_SCENE(k_shadow_rays_lane_count, grid_sh, block, ctx, fp, q, d_ctr);
+    else if (ctx->shadow_per_ray && ctx->shadow_queue) LAUNCH_SCENE(k_shadow_rays, grid_sh, block, ctx, fp, q, d_ctr);
+    else if (ctx->shadow_per_ray) LAUNCH_SCENE(k_shadow_rays_lane, grid_sh, block, ctx, fp, q, d_ctr);
     else LAUNCH_SCENE(k_shadow, dim3(std::min<unsigned>((q.cap + 255) / 256, 2 * cus8)), block, ctx, fp, q, d_ctr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
@@ -1263,6 +1268,8 @@ static int render_impl(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_
         }
         fprintf(stderr, "[pm] group kernel ticks per phase (centre query, collect, pass 1, pass 2, rank, sum): %llu %llu %llu %llu %llu %llu; shared sets %llu, candidates %llu\n", hc.tphase[0],
                 hc.tphase[1], hc.tphase[2], hc.tphase[3], hc.tphase[4], hc.tphase[5], hc.tphase[7], hc.tphase[6]);
+        if (hc.walk[0]) fprintf(stderr, "[pm] shadow pass through the sphere grid: %llu sphere tests, %llu cells entered by %u rays; the waves made %llu steps and %llu rounds of tests\n",
+                                hc.tests[2], hc.walk[0], 25u * n_sp, hc.walk[1], hc.walk[2]);
     }
     (void)d_ctr;
 #ifdef PM_WAVE_TIMES

@@ -30,7 +30,7 @@ struct FrameParams {
     int rank, world;
 };
 
-struct Counters { uint32_t n_sp, n_complex, n_secondary, n_groups, n_left[2][4], pad, n_sgroups, n_early, n_pieces, overflow, n_sp0, n_bounced, done_primary, done_secondary; unsigned long long tests[4]; uint32_t why[8]; unsigned long long tphase[8]; uint32_t ghist[2][32]; };   // n_left[k][p]: shade points that part p of map k's group launches left to the per-query gather
+struct Counters { uint32_t n_sp, n_complex, n_secondary, n_groups, n_left[2][4], pad, n_sgroups, n_early, n_pieces, overflow, n_sp0, n_bounced, done_primary, done_secondary; unsigned long long tests[4]; unsigned long long walk[4]; uint32_t why[8]; unsigned long long tphase[8]; uint32_t ghist[2][32]; };   // n_left[k][p]: shade points that part p of map k's group launches left to the per-query gather
 
 // The frame's counts live on the device: nothing of a frame waits for the host.  n_sp0 = shade points of primary hits (slots
 // 0 .. n_sp0, grouped by pixel tile), written by k_mark_primary behind k_primary; n_bounced = shade points of bounced pixels
@@ -104,7 +104,7 @@ __device__ inline void wave_add_count(unsigned long long *to, uint32_t mine) {
 template <int MODE, bool COUNT>
 __device__ inline void primary_body(const SceneView &gs, const FrameParams &fp, uint32_t *pane, Counters *ctr, const SPQueue &q, uint32_t *complex_list, uint2 *groups) {
     extern __shared__ __align__(16) unsigned char smem[];
-    TestCount tc = {0u, 0u};
+    TestCount tc = {0u, 0u, 0u, 0u, 0u};
     SceneView sv = gs;
     if (MODE == SCENE_LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
     int x, y;
@@ -402,11 +402,13 @@ __global__ __launch_bounds__(256) void k_sp_classify(SPQueue q, const uint32_t *
 // The work is cut 25 times finer, so every SIMD stays busy until the end and the pass shares the device better with the
 // map builds beside it (default scene: the pass itself 0.24 -> 0.28 ms, the step 3.10 -> 3.05 ms; 10 000 spheres, where a
 // ray ends at its first blocker or walks cells all the way to the light: step 13.3 -> 11.8 ms).
-template <int MODE, bool COUNT>
+template <int MODE, bool COUNT, bool QUEUED>
 __device__ inline void shadow_rays_body(const SceneView &gs, const FrameParams &fp, const SPQueue &q, Counters *ctr) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int blocked[10];
-    TestCount tc = {0u, 0u};
+    constexpr bool WAVE_WALK = MODE == SCENE_GRID && QUEUED;     // the wave's rays share a test queue (shadow_blocked_wave)
+    __shared__ WalkBuf walk[WAVE_WALK ? 4 : 1];
+    TestCount tc = {0u, 0u, 0u, 0u, 0u};
     SceneView sv = gs;
     if (MODE == SCENE_LDS) { sv = stage_scene(gs, smem); }
     const uint32_t n_sp = sp_total(ctr, q.cap);      // launched for the queue's capacity: blocks take groups of 10 shade points in turn
@@ -417,19 +419,24 @@ __device__ inline void shadow_rays_body(const SceneView &gs, const FrameParams &
         const uint32_t s = g * 10u + local;
         const bool live = threadIdx.x < 250u && s < n_sp;
         V3 p = {0, 0, 0}, nrm = {0, 0, 0}, shadow_ray = {0, 0, 0};
+        double dt = 0, max_dist = 0;
+        int obj = -1;
         if (live) {
             p = {q.geo[0 * (size_t)q.cap + s], q.geo[1 * (size_t)q.cap + s], q.geo[2 * (size_t)q.cap + s]};
-            const int obj = q.obj[s];
+            obj = q.obj[s];
             const uint64_t IK = item_key(fp.K, (uint64_t)q.pixel[s] * 32u + (q.node[s] & 31u));
             const double x0 = draw(IK, 1 + 3 * i) * 2 - 1;
             const double z0 = draw(IK, 2 + 3 * i) * 2 + 3;
             const double y0 = 4.95;
             shadow_ray.x = x0 - p.x; shadow_ray.y = y0 - p.y; shadow_ray.z = z0 - p.z;
-            const double max_dist = shadow_ray.x * shadow_ray.x + shadow_ray.y * shadow_ray.y + shadow_ray.z * shadow_ray.z;
+            max_dist = shadow_ray.x * shadow_ray.x + shadow_ray.y * shadow_ray.y + shadow_ray.z * shadow_ray.z;
             normalize(shadow_ray);
-            const double dt = draw(IK, 3 + 3 * i);
-            if (shadow_blocked<MODE>(sv, p, shadow_ray, dt, obj, max_dist, COUNT ? &tc : nullptr)) atomicAdd(&blocked[local], 1);
+            dt = draw(IK, 3 + 3 * i);
         }
+        bool dark;
+        if (WAVE_WALK) dark = shadow_blocked_wave(sv, walk[threadIdx.x >> 6], live, p, shadow_ray, dt, obj, max_dist, COUNT ? &tc : nullptr);
+        else dark = live && shadow_blocked<MODE>(sv, p, shadow_ray, dt, obj, max_dist, COUNT ? &tc : nullptr);
+        if (dark) atomicAdd(&blocked[local], 1);
         __syncthreads();
         if (live && i == 24u) {        // the direct term uses the direction of the LAST shadow ray, src/Raytrace.cpp:207-212
             nrm = {q.geo[3 * (size_t)q.cap + s], q.geo[4 * (size_t)q.cap + s], q.geo[5 * (size_t)q.cap + s]};
@@ -444,12 +451,17 @@ __device__ inline void shadow_rays_body(const SceneView &gs, const FrameParams &
         }
         __syncthreads();               // `blocked` is cleared for the next group
     }
-    if (COUNT) { wave_add_count(&ctr->tests[2], tc.spheres); wave_add_count(&ctr->tests[3], tc.planes); }
+    if (COUNT) { wave_add_count(&ctr->tests[2], tc.spheres); wave_add_count(&ctr->tests[3], tc.planes); wave_add_count(&ctr->walk[0], tc.cells); wave_add_count(&ctr->walk[1], tc.wsteps); wave_add_count(&ctr->walk[2], tc.wtests); }
 }
 template <int MODE>
-__global__ __launch_bounds__(256) void k_shadow_rays(SceneView gs, FrameParams fp, SPQueue q, Counters *ctr) { shadow_rays_body<MODE, false>(gs, fp, q, ctr); }
+__global__ __launch_bounds__(256) void k_shadow_rays(SceneView gs, FrameParams fp, SPQueue q, Counters *ctr) { shadow_rays_body<MODE, false, true>(gs, fp, q, ctr); }
 template <int MODE>
-__global__ __launch_bounds__(256) void k_shadow_rays_count(SceneView gs, FrameParams fp, SPQueue q, Counters *ctr) { shadow_rays_body<MODE, true>(gs, fp, q, ctr); }
+__global__ __launch_bounds__(256) void k_shadow_rays_count(SceneView gs, FrameParams fp, SPQueue q, Counters *ctr) { shadow_rays_body<MODE, true, true>(gs, fp, q, ctr); }
+// every ray walks and tests on its own (PM_SHADOW_QUEUE=0: A/B runs of the sphere grid's walk)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_shadow_rays_lane(SceneView gs, FrameParams fp, SPQueue q, Counters *ctr) { shadow_rays_body<MODE, false, false>(gs, fp, q, ctr); }
+template <int MODE>
+__global__ __launch_bounds__(256) void k_shadow_rays_lane_count(SceneView gs, FrameParams fp, SPQueue q, Counters *ctr) { shadow_rays_body<MODE, true, false>(gs, fp, q, ctr); }
 
 // One draw from a work counter per wave.  Out of line on purpose: inlined into the scheduling loop, the
 // lane-0 branch was threaded into the loop's control flow and lanes 1..63 were sent round the loop on their own.

@@ -83,10 +83,6 @@ PM_WAVE_REDUCE(wave_and_u32, uint32_t, and_op)
 __device__ inline int lane_rank(unsigned long long mask) {   // set bits of mask below this lane
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
-__device__ inline void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
 __device__ inline unsigned long long readlane_u64(unsigned long long v, int l) {
     uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
     uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);

@@ -1,0 +1,30 @@
+"""Statistics of the shadow pass of the 10 000 sphere scene: tests and grid cells per ray, wave-level rounds (PM_DEBUG print
+of the counting variant), and the pass's time.  GPU only."""
+import os, sys, time
+os.environ["PM_DEBUG"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import raytracer_amd as ra
+from raytracer_amd.frame import GpuFrame
+
+ctx = ra.Context(0)
+ctx.upload_scene(ra.many_spheres_scene())
+frame = GpuFrame(ctx, 1440, 1440, 1000000, 12345)
+for _ in range(2):
+    frame.step()
+torch.cuda.synchronize()
+os.environ.pop("PM_DEBUG")
+ms = []
+for _ in range(5):
+    frame.build_maps(); st = frame.render(); ms.append((st.ms_primary, st.ms_secondary, st.ms_shadow, st.ms_total))
+import hashlib
+print("pane sha1", hashlib.sha1(frame.gather_pane().cpu().numpy().tobytes()).hexdigest())
+print("ms primary/secondary/shadow/total:", [tuple(round(x, 3) for x in m) for m in ms])
+ms = []
+for _ in range(5):
+    st = frame.render(); ms.append((st.ms_primary, st.ms_secondary, st.ms_shadow, st.ms_total))
+print("alone (maps kept) ms primary/secondary/shadow/total:", [tuple(round(x, 3) for x in m) for m in ms])
+os.environ["PM_DEBUG"] = "1"
+frame.flags |= ra.PM_FLAG_COUNT_TESTS
+st = frame.render()
+print("tests primary", st.tests_primary_sphere, st.tests_primary_plane, "shadow", st.tests_shadow_sphere, st.tests_shadow_plane, "sp", st.absorb_points)
