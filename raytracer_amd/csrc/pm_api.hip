@@ -55,7 +55,7 @@ constexpr size_t ES_OFF_TMP = 0;                                                
 constexpr size_t ES_OFF_FLAG = ES_OFF_TMP + es_align(ES_MAX * sizeof(pm_photon));  // one byte per attempt
 constexpr size_t ES_OFF_COUNTS = ES_OFF_FLAG + es_align(ES_MAX);                   // successes per block of 256 attempts
 constexpr size_t ES_OFF_OFFS = ES_OFF_COUNTS + es_align((ES_MAX / 256) * 4);       // their exclusive scan + the total
-constexpr size_t ES_BYTES = ES_OFF_OFFS + es_align((ES_MAX / 256 + 1) * 8);
+constexpr size_t ES_BYTES = ES_OFF_OFFS + es_align((ES_MAX / 256 + 2) * 8);        // + the work counter of k_emit_stream
 static __device__ __align__(256) unsigned char scratch[ES_BYTES];
 
 constexpr size_t LDS_SCENE_MAX = 48 * 1024;   // scenes up to this size are staged in LDS; larger ones are read from global memory
@@ -86,6 +86,8 @@ struct pm_ctx {
     int nprims = 0, stride = 0;
     double yield[2] = {0.60, 0.36};   // stored photons per emission attempt (global, caustic): the reference scene's to begin with, then
                                       // what the last map of this scene showed (sizes the one emission range a map is made from)
+    bool emit_stream = true;          // sphere grid: emission as a stream of attempts per wave (PM_EMIT_STREAM=0: one attempt per lane, for A/B runs)
+    int emit_blocks = 512;            // blocks of k_emit_stream per launch: two maps side by side fill 256 CUs x 4 blocks (PM_EMIT_BLOCKS)
     bool shadow_queue = true;         // sphere grid: the rays of a wave share a queue of tests (PM_SHADOW_QUEUE=0: every ray tests on its own, for A/B runs)
     bool shadow_per_ray = true;       // one lane per shadow ray rather than per shade point (PM_SHADOW_PER_RAY=0: the latter, for A/B runs)
     int scene_mode = SCENE_LDS;   // SCENE_LDS: staged per block; SCENE_GLOBAL: read in place; SCENE_GRID: in place, through the sphere grid
@@ -384,6 +386,8 @@ extern "C" int pm_scene_upload(pm_ctx *ctx, const pm_prim *prims, int32_t n) {
     }
     if (const char *e = getenv("PM_SHADOW_PER_RAY")) ctx->shadow_per_ray = e[0] != '0';
     if (const char *e = getenv("PM_SHADOW_QUEUE")) ctx->shadow_queue = e[0] != '0';
+    if (const char *e = getenv("PM_EMIT_STREAM")) ctx->emit_stream = e[0] != '0';
+    if (const char *e = getenv("PM_EMIT_BLOCKS")) { int v = atoi(e); if (v > 0 && v <= 65536) ctx->emit_blocks = v; }
     return PM_OK;
 }
 
@@ -399,13 +403,13 @@ extern "C" int pm_scene_upload(pm_ctx *ctx, const pm_prim *prims, int32_t n) {
 // attempts [a0, a0+count) -> first `cap` successes, in attempt order, into d_out, on the slot's stream with the slot's
 // scratch; the number of successes in the range lands in *h_got (pinned) when the stream gets there.
 // total != NULL: wait for it.
-struct EmitScratch { pm_photon *tmp; uint8_t *flag; uint32_t *counts; uint64_t *offs; };
+struct EmitScratch { pm_photon *tmp; uint8_t *flag; uint32_t *counts; uint64_t *offs; };   // offs: nb + 1 offsets, then the work counter of k_emit_stream
 static int slot_scratch(BuildSlot &sl, uint64_t count, EmitScratch &es) {
     uint32_t nb = (uint32_t)((count + 255) / 256);
     PMCHK(sl.emit_tmp.ensure(count * sizeof(pm_photon)));
     PMCHK(sl.emit_flag.ensure(count));
     PMCHK(sl.emit_counts.ensure((size_t)nb * 4));
-    PMCHK(sl.emit_offs.ensure(((size_t)nb + 1) * 8));
+    PMCHK(sl.emit_offs.ensure(((size_t)nb + 2) * 8));
     es = {sl.emit_tmp.as<pm_photon>(), sl.emit_flag.as<uint8_t>(), sl.emit_counts.as<uint32_t>(), sl.emit_offs.as<uint64_t>()};
     return PM_OK;
 }
@@ -416,7 +420,14 @@ static int emit_range_on(pm_ctx *ctx, hipStream_t stream, const EmitScratch &es,
     uint32_t nb = (uint32_t)((count + 255) / 256);
     uint64_t K = stream_key(seed, kind == PM_MAP_GLOBAL ? KIND_EMIT_GLOBAL : KIND_EMIT_CAUSTIC);
     V3 light = {lc[0], lc[1], lc[2]};
-    LAUNCH_SCENE_ON(k_emit, dim3(nb), dim3(256), ctx, stream, kind, K, light, a0, count, es.tmp, es.flag, es.counts);
+    if (ctx->scene_mode == SCENE_GRID && ctx->emit_stream) {
+        // a resident grid of waves that draw attempts from a counter (pm_trace.h)
+        uint32_t *next = reinterpret_cast<uint32_t *>(es.offs + nb + 1);
+        HIPCHK(hipMemsetAsync(next, 0, 4, stream));
+        hipLaunchKernelGGL(k_emit_stream, dim3(std::min<uint32_t>(nb, (uint32_t)ctx->emit_blocks)), dim3(256), 0, stream, ctx->gv, kind, K, light, a0, count, es.tmp, es.flag, next);
+        hipLaunchKernelGGL(k_flag_counts, dim3(nb), dim3(256), 0, stream, es.flag, count, es.counts);
+    } else
+        LAUNCH_SCENE_ON(k_emit, dim3(nb), dim3(256), ctx, stream, kind, K, light, a0, count, es.tmp, es.flag, es.counts);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, es.counts, es.offs, nb, d_running, bounds_init);
     hipLaunchKernelGGL(k_emit_scatter, dim3(nb), dim3(256), 0, stream, es.tmp, es.flag, es.offs, count, d_out, cap);
     HIPCHK(hipGetLastError());
@@ -435,6 +446,14 @@ static int emit_range(pm_ctx *ctx, BuildSlot &sl, int kind, uint64_t seed, const
     return emit_range_on(ctx, sl.stream, es, kind, seed, lc, a0, count, d_out, cap, h_got, total, d_running, bounds_init);
 }
 
+#ifdef PM_TRACE_STATS
+extern "C" int pm_trace_stats(unsigned long long *out16, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_trace_stats), 16 * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace_stats), z, 16 * 8) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 extern "C" int pm_emit_range(pm_ctx *ctx, int32_t map_kind, uint64_t seed, const double light_color[3], uint64_t attempt_begin,
                              uint64_t attempt_count, pm_photon *d_out, uint64_t cap, uint64_t *out_count) {
     if (!ctx || !light_color || !out_count || (!d_out && cap)) return fail(PM_EINVAL, "pm_emit_range: NULL argument");

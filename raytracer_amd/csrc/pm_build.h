@@ -6,6 +6,7 @@
 #include "pm_morton.h"
 #include "pm_grid.h"
 #include "pm_sort.h"
+#include "pm_trace.h"
 #include "../../include/raytracer_amd.h"
 
 namespace pm {
@@ -95,6 +96,130 @@ __global__ __launch_bounds__(256) void k_emit(SceneView gs, int map_kind, uint64
         flag[t] = stored ? 1 : 0;
     }
     int c = __syncthreads_count(stored ? 1 : 0);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = (uint32_t)c;
+}
+
+// The same attempts through the sphere grid of a large scene, as a stream (pm_trace.h): a wave keeps 64 attempts in flight.
+// A lane whose photon is absorbed, lost or stored takes the next attempt from the launch's counter while its neighbours go
+// on with theirs; a lane whose photon bounces starts the next segment in place.  Lanes are served in batches (16 waiting, or
+// nobody walking), since serving runs the bounce arithmetic and the set-up of a walk for the whole wave.  flag[t] / tmp[t]
+// are indexed by the attempt, so the order of the photons does not depend on which lane traced what; the successes per
+// block of 256 attempts are counted afterwards from the flags (k_flag_counts).
+constexpr int TRACE_SERVE_MIN = 32;     // 8: 6.1 ms for both maps of the 10 000 sphere scene, 16: 3.9, 24: 3.5, 32: 3.4, 48: 3.5
+// four waves per SIMD: 128 registers without a spill (3: 135 registers, 4.05 ms for both maps; 4: 3.9; 5 and 6 spill in the walk: 5.5, 8.2)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_emit_stream(SceneView sv, int map_kind, uint64_t K, V3 light_color, uint64_t a0, uint64_t count,
+                                                      pm_photon *tmp, uint8_t *flag, uint32_t *next) {
+    __shared__ TraceBuf bufs[4];
+    WaveTracer<false> tr(sv, bufs[threadIdx.x >> 6]);
+    const int lane = threadIdx.x & 63;
+    bool have = false, more = true, specular_bounce = false;
+    uint64_t t = 0, IK = 0;
+    uint32_t j = 0;
+    V3 power = light_color;
+    int bounces = 0, exclude = -1;
+    for (;;) {
+        const bool fin = tr.finished();
+        const unsigned long long m_fin = __ballot(fin), m_have = __ballot(have);
+        if (!m_have && !more) break;
+        const int n_busy = __popcll(m_have & ~m_fin), n_serve = __popcll(m_fin) + (more ? 64 - __popcll(m_have) : 0);
+        TRACE_STAT(8, 1);
+        if (n_serve > 0 && (n_serve >= TRACE_SERVE_MIN || n_busy == 0)) {
+            TRACE_STAT(0, 1); TRACE_STAT(1, __popcll(m_fin));
+            bool fresh = false;
+            V3 src = {0, 0, 0}, dir = {0, 0, 0};
+            if (fin) {
+                // the body of the reference's bounce loop behind the intersection, src/PhotonMap.cpp:300-367 / :412-484
+                V3 res = {0, 0, 0}, nrm = {0, 0, 0};
+                dir = {tr.wb.dx[lane], tr.wb.dy[lane], tr.wb.dz[lane]};
+                const int obj = tr.result(res, nrm);
+                bool stored = false, again = false;
+                if (obj >= 0) {
+                    double chance = draw(IK, j++);
+                    if (bounces > 3) chance = 1;
+                    double kd = sv.f(G_DIFFUSE, obj), ks = sv.f(G_SPECULAR, obj), kt = sv.f(G_TRANSMISSION, obj);
+                    if (chance < kd + ks) {
+                        V3 n1 = nrm;
+                        double k = n1.x * dir.x + n1.y * dir.y + n1.z * dir.z;
+                        n1.x *= k; n1.y *= k; n1.z *= k;
+                        n1.x *= 2; n1.y *= 2; n1.z *= 2;
+                        src = res;
+                        dir.x = dir.x - n1.x; dir.y = dir.y - n1.y; dir.z = dir.z - n1.z;
+                        normalize(dir);
+                        power.x *= (double)sv.rgb[0 * sv.stride + obj]; power.y *= (double)sv.rgb[1 * sv.stride + obj]; power.z *= (double)sv.rgb[2 * sv.stride + obj];
+                        if (map_kind == PM_MAP_GLOBAL) exclude = obj;
+                        specular_bounce = true;
+                        again = true;
+                    } else if (chance < kd + ks + kt) {
+                        double n = 1 / sv.f(G_REFRACTION, obj);
+                        double d = nrm.x * dir.x + nrm.y * dir.y + nrm.z * dir.z;
+                        V3 n1 = {nrm.x * d, nrm.y * d, nrm.z * d};
+                        n1.x = dir.x - n1.x; n1.y = dir.y - n1.y; n1.z = dir.z - n1.z;
+                        n1.x *= n; n1.y *= n; n1.z *= n;
+                        double sq = sqrt(1 - (n * n) * (1 - d * d));
+                        V3 n2 = {nrm.x * sq, nrm.y * sq, nrm.z * sq};
+                        n1.x += -n2.x; n1.y += -n2.y; n1.z += -n2.z;
+                        src.x = res.x + n1.x * 0.01; src.y = res.y + n1.y * 0.01; src.z = res.z + n1.z * 0.01;
+                        dir = n1;
+                        normalize(dir);
+                        exclude = -1;
+                        specular_bounce = true;
+                        again = true;
+                    } else if (!(map_kind == PM_MAP_CAUSTIC && !specular_bounce)) {
+                        pm_photon ph;
+                        ph.x = (float)res.x; ph.y = (float)res.y; ph.z = (float)res.z;
+                        ph.power[0] = (uint8_t)fastfloor(power.x * 0xFF);
+                        ph.power[1] = (uint8_t)fastfloor(power.y * 0xFF);
+                        ph.power[2] = (uint8_t)fastfloor(power.z * 0xFF);
+                        ph.power[3] = 255;
+                        ph.dx = (float)dir.x; ph.dy = (float)dir.y; ph.dz = (float)dir.z;
+                        ph.bounce = (int8_t)bounces;
+                        ph.pad[0] = ph.pad[1] = ph.pad[2] = 0;
+                        tmp[t] = ph;
+                        stored = true;
+                    }
+                }
+                if (again && bounces < EMIT_MAX_BOUNCES) { bounces++; fresh = true; }
+                else { flag[t] = stored ? 1 : 0; have = false; }
+            }
+            if (more) {
+                // the lanes without an attempt take the next ones of the launch, in lane order
+                const unsigned long long m_need = __ballot(!have);
+                const uint32_t n = (uint32_t)__popcll(m_need);
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(next, n);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                const uint64_t mine = (uint64_t)base + (uint64_t)__popcll(m_need & tr.below);
+                TRACE_STAT(2, n);
+                if (!have && mine < count) {
+                    t = mine;
+                    IK = item_key(K, a0 + t);
+                    j = 0;
+                    power = light_color;
+                    double x0 = draw(IK, j++) * 2 - 1;
+                    double z0 = draw(IK, j++) * 2 + 3;
+                    src = {x0, 4.95, z0};
+                    double sin_theta = sqrt(draw(IK, j++));
+                    double cos_theta = sqrt(1 - sin_theta * sin_theta);
+                    double psi = draw(IK, j++) * 6.2831853;
+                    double sp, cp;
+                    det_sincos(psi, sp, cp);
+                    dir = {sin_theta * cp, map_kind == PM_MAP_GLOBAL ? -cos_theta : -2 * cos_theta, sin_theta * sp};
+                    normalize(dir);
+                    bounces = 1; exclude = -1; specular_bounce = false;
+                    have = true; fresh = true;
+                }
+                if ((uint64_t)base + n >= count) more = false;
+            }
+            tr.start(fresh, src, dir, 0.0, exclude, 0.0);
+            continue;
+        }
+        tr.pump();
+    }
+}
+// successes per block of 256 attempts, from the flags
+__global__ __launch_bounds__(256) void k_flag_counts(const uint8_t *flag, uint64_t count, uint32_t *block_counts) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = __syncthreads_count(t < count && flag[t] != 0);
     if (threadIdx.x == 0) block_counts[blockIdx.x] = (uint32_t)c;
 }
 

@@ -44,6 +44,18 @@ def test_emit_range_static_equals_emit_range_twice(gpu_ctx, orc, kind):
     assert rec4[:n4].tobytes() == want.tobytes()
 
 
+def test_emit_range_static_through_the_sphere_grid(gpu_ctx):
+    """10 000 spheres: the emission is the stream kernel (pm_trace.h), whose work counter lives in the scratch too."""
+    import raytracer_amd as ra
+    gpu_ctx.upload_scene(ra.many_spheres_scene())
+    try:
+        n1, _ = _pair(gpu_ctx, 0, 99, 0, ra.capi.PM_EMIT_STATIC_MAX_ATTEMPTS, ra.capi.PM_EMIT_STATIC_MAX_ATTEMPTS)
+        n2, _ = _pair(gpu_ctx, 1, 99, 31, 3000, 3000)
+        assert n2 < n1
+    finally:
+        gpu_ctx.upload_scene(ra.default_scene())
+
+
 def test_emit_range_static_rejects_what_the_scratch_cannot_hold(gpu_ctx):
     import torch
     import raytracer_amd as ra
