@@ -110,7 +110,7 @@ constexpr int TRACE_SERVE_MIN = 32;     // 8: 6.1 ms for both maps of the 10 000
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_emit_stream(SceneView sv, int map_kind, uint64_t K, V3 light_color, uint64_t a0, uint64_t count,
                                                       pm_photon *tmp, uint8_t *flag, uint32_t *next) {
     __shared__ TraceBuf bufs[4];
-    WaveTracer<false> tr(sv, bufs[threadIdx.x >> 6]);
+    WaveTracer<false, true> tr(sv, bufs[threadIdx.x >> 6]);
     const int lane = threadIdx.x & 63;
     bool have = false, more = true, specular_bounce = false;
     uint64_t t = 0, IK = 0;

@@ -358,121 +358,9 @@ __device__ inline bool shadow_blocked(const SceneView &s, const V3 &p, const V3 
     return hit;
 }
 
-// The same any-hit query for the 64 shadow rays of a wave at once (SCENE_GRID; every lane of the wave calls it, `live` or
-// not).  Lane by lane the walk above leaves the SIMD mostly idle in the tests: a cell holds 0.7 spheres on average, so in
-// every step the wave runs the test loop as often as its fullest cell asks for, for the few lanes that have that many
-// (10 000 spheres, 1440 x 1440: 14.9 M rounds of tests by the waves for 174 M tests by the lanes: 18 % of the lanes busy).
-// Here stepping and testing are two phases.  Every lane steps its own ray from cell to cell and appends (ray, reference)
-// pairs of the cells it enters to a queue of the wave in LDS; whenever 64 pairs are queued the wave tests them, one per
-// lane, with the ray's operands read from LDS: full rounds, whatever cells the pairs came from.  A ray runs ahead of its
-// queued tests by a few cells; what it queues after its blocker is tested for nothing, and the answer is the same OR over
-// the same tests (a ray is blocked when ANY sphere in a cell it enters before t_stop is hit within max_dist).
-constexpr int WALK_CAP = 192;
-struct WalkBuf {
-    double ox[64], oy[64], oz[64], dx[64], dy[64], dz[64], dt[64], lim[64];
-    int skip[64];
-    uint32_t hit[64];
-    uint32_t qref[WALK_CAP];
-    unsigned char qsrc[WALK_CAP];
-};
 __device__ inline void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-}
-__device__ inline bool shadow_blocked_wave(const SceneView &s, WalkBuf &wb, bool live, const V3 &p, const V3 &ray, double dt, int obj, double max_dist, TestCount *tc = nullptr) {
-    const SceneGrid &G = s.grid;
-    const int lane = threadIdx.x & 63;
-    const unsigned long long below = (1ULL << lane) - 1ULL;
-    // planes and the spheres outside the grid: lane by lane, as in shadow_blocked
-    bool blocked = false;
-    if (live) {
-        V3 result = {0, 0, 0};
-        for (int k = 0; k < G.nloose && !blocked; k++) {
-            const int i = G.loose[k];
-            if (i == obj || !prim_hit(s, i, p, ray, dt, result, tc)) continue;
-            double ds = (p.x - result.x) * (p.x - result.x) + (p.y - result.y) * (p.y - result.y) + (p.z - result.z) * (p.z - result.z);
-            blocked = !(ds > max_dist);
-        }
-    }
-    wb.ox[lane] = p.x; wb.oy[lane] = p.y; wb.oz[lane] = p.z; wb.dx[lane] = ray.x; wb.dy[lane] = ray.y; wb.dz[lane] = ray.z;
-    wb.dt[lane] = dt; wb.lim[lane] = max_dist; wb.skip[lane] = obj; wb.hit[lane] = 0u;
-    // set-up of the walk: grid_walk's
-    bool alive = live && !blocked;
-    double t0 = 0, t1 = __builtin_inf(), invx = 0, invy = 0, invz = 0;
-    if (alive) alive = grid_clip(G.lo[0], G.hi[0], p.x, ray.x, invx, t0, t1);
-    if (alive) alive = grid_clip(G.lo[1], G.hi[1], p.y, ray.y, invy, t0, t1);
-    if (alive) alive = grid_clip(G.lo[2], G.hi[2], p.z, ray.z, invz, t0, t1);
-    if (alive) alive = t0 <= t1;
-    const double dd = ray.x * ray.x + ray.y * ray.y + ray.z * ray.z;
-    const double t_stop = sqrt(max_dist / dd) * (1.0 + 1e-9) + 1e-9;
-    double tx = 0, ty = 0, tz = 0;
-    int ix = 0, iy = 0, iz = 0;
-    if (alive) {
-        ix = grid_enter(G.lo[0], G.cs[0], G.inv_cs[0], G.rx, p.x, ray.x, invx, t0, tx);
-        iy = grid_enter(G.lo[1], G.cs[1], G.inv_cs[1], G.ry, p.y, ray.y, invy, t0, ty);
-        iz = grid_enter(G.lo[2], G.cs[2], G.inv_cs[2], G.rz, p.z, ray.z, invz, t0, tz);
-    }
-    const int sx = ray.x > 0 ? 1 : -1, sy = ray.y > 0 ? 1 : -1, sz = ray.z > 0 ? 1 : -1;
-    const double dtx = G.cs[0] * fabs(invx), dty = G.cs[1] * fabs(invy), dtz = G.cs[2] * fabs(invz);
-    const int cx = sx, cy = sy * G.rx, cz = sz * G.rx * G.ry;
-    int c = (iz * G.ry + iy) * G.rx + ix;
-    int guard = G.rx + G.ry + G.rz + 3;
-    uint32_t r = 0, e = 0;                      // references of the lane's cell that are not queued yet
-    if (alive && t0 > t_stop) alive = false;
-    if (alive) { r = G.cell_start[c]; e = G.cell_start[c + 1]; if (tc) tc->cells++; }
-    int qn = 0;                                 // queued pairs (wave-uniform)
-    wave_lds_fence();
-    for (;;) {
-        // queue: one reference per lane and turn, lanes in order
-        for (;;) {
-            const bool has = alive && r < e;
-            const unsigned long long m = __ballot(has);
-            if (!m) break;
-            const int n = __popcll(m);
-            if (qn + n > WALK_CAP) break;
-            if (has) { const int at = qn + __popcll(m & below); wb.qref[at] = r; wb.qsrc[at] = (unsigned char)lane; r++; }
-            qn += n;
-        }
-        const bool can_step = alive && r >= e;
-        const bool any_step = __ballot(can_step) != 0ULL;
-        if (qn >= 64 || (qn > 0 && !any_step)) {
-            // one round of tests: the last pairs of the queue, one per lane
-            wave_lds_fence();
-            const int take = qn < 64 ? qn : 64;
-            if (tc && wave_first_lane()) tc->wtests++;
-            if (lane < take) {
-                const int at = qn - 1 - lane, src = wb.qsrc[at];
-                const double *P = G.packed + (size_t)wb.qref[at] * 8;
-                if ((int)__double_as_longlong(P[7]) != wb.skip[src]) {
-                    if (tc) tc->spheres++;
-                    const V3 o = {wb.ox[src], wb.oy[src], wb.oz[src]}, d = {wb.dx[src], wb.dy[src], wb.dz[src]};
-                    V3 result = {0, 0, 0};
-                    if (sphere_hit_packed(P, o, d, wb.dt[src], result)) {
-                        double ds = (o.x - result.x) * (o.x - result.x) + (o.y - result.y) * (o.y - result.y) + (o.z - result.z) * (o.z - result.z);
-                        if (!(ds > wb.lim[src])) wb.hit[src] = 1u;
-                    }
-                }
-            }
-            qn -= take;
-            wave_lds_fence();
-            if (alive && wb.hit[lane]) { alive = false; blocked = true; r = e; }
-            continue;
-        }
-        if (!any_step) break;                   // nothing queued, nobody walking: the wave is done
-        if (tc && wave_first_lane()) tc->wsteps++;
-        if (can_step) {
-            const bool bx = tx <= ty && tx <= tz, by = !bx && ty <= tz, bz = !bx && !by;
-            const double t_in = bx ? tx : (by ? ty : tz);
-            ix += bx ? sx : 0; iy += by ? sy : 0; iz += bz ? sz : 0;
-            tx += bx ? dtx : 0.0; ty += by ? dty : 0.0; tz += bz ? dtz : 0.0;
-            c += bx ? cx : (by ? cy : cz);
-            guard--;
-            alive = t_in <= t1 && guard > 0 && !(t_in > t_stop) &&
-                    !((unsigned)ix >= (unsigned)G.rx || (unsigned)iy >= (unsigned)G.ry || (unsigned)iz >= (unsigned)G.rz);
-            if (alive) { r = G.cell_start[c]; e = G.cell_start[c + 1]; if (tc) tc->cells++; }
-        }
-    }
-    return blocked || (live && wb.hit[lane] != 0u);
 }
 
 // Stage the SoA scene into LDS (all threads of the block call this, then __syncthreads()).

@@ -18,6 +18,7 @@
 #include "pm_grid.h"
 #include "pm_tile.h"
 #include "pm_pair.h"
+#include "pm_trace.h"
 
 namespace pm {
 
@@ -406,8 +407,8 @@ template <int MODE, bool COUNT, bool QUEUED>
 __device__ inline void shadow_rays_body(const SceneView &gs, const FrameParams &fp, const SPQueue &q, Counters *ctr) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int blocked[10];
-    constexpr bool WAVE_WALK = MODE == SCENE_GRID && QUEUED;     // the wave's rays share a test queue (shadow_blocked_wave)
-    __shared__ WalkBuf walk[WAVE_WALK ? 4 : 1];
+    constexpr bool WAVE_WALK = MODE == SCENE_GRID && QUEUED;     // the wave's rays share a queue of tests (pm_trace.h)
+    __shared__ TraceBuf walk[WAVE_WALK ? 4 : 1];
     TestCount tc = {0u, 0u, 0u, 0u, 0u};
     SceneView sv = gs;
     if (MODE == SCENE_LDS) { sv = stage_scene(gs, smem); }
@@ -434,8 +435,12 @@ __device__ inline void shadow_rays_body(const SceneView &gs, const FrameParams &
             dt = draw(IK, 3 + 3 * i);
         }
         bool dark;
-        if (WAVE_WALK) dark = shadow_blocked_wave(sv, walk[threadIdx.x >> 6], live, p, shadow_ray, dt, obj, max_dist, COUNT ? &tc : nullptr);
-        else dark = live && shadow_blocked<MODE>(sv, p, shadow_ray, dt, obj, max_dist, COUNT ? &tc : nullptr);
+        if (WAVE_WALK) {
+            WaveTracer<true, false> tr(sv, walk[threadIdx.x >> 6], COUNT ? &tc : nullptr);
+            tr.start(live, p, shadow_ray, dt, obj, max_dist);
+            while (__ballot(tr.pending && !tr.finished()) != 0ULL) tr.pump();
+            dark = live && tr.blocked();
+        } else dark = live && shadow_blocked<MODE>(sv, p, shadow_ray, dt, obj, max_dist, COUNT ? &tc : nullptr);
         if (dark) atomicAdd(&blocked[local], 1);
         __syncthreads();
         if (live && i == 24u) {        // the direct term uses the direction of the LAST shadow ray, src/Raytrace.cpp:207-212

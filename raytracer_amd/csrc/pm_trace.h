@@ -47,7 +47,9 @@ static __device__ unsigned long long g_trace_stats[16];
 #define TRACE_STAT(k, v) do { } while (0)
 #endif
 
-template <bool ANYHIT>
+// EAGER: with few lanes still walking the ring fills slowly; test what is queued early, so that the lanes that wait for
+// their result (and for their next ray) do not wait for it
+template <bool ANYHIT, bool EAGER>
 struct WaveTracer {
     const SceneView &s;
     TraceBuf &wb;
@@ -229,7 +231,7 @@ struct WaveTracer {
         const bool can_step = walking && r >= e;
         const bool any_step = __ballot(can_step) != 0ULL;
         const uint32_t nwalk = (uint32_t)__popcll(__ballot(walking)), avail = tail - head;
-        const uint32_t want = 2u * nwalk < 64u ? 2u * nwalk : 64u;          // few walkers: the ring fills slowly, do not let the others wait
+        const uint32_t want = EAGER && 2u * nwalk < 64u ? 2u * nwalk : 64u;
         if (avail > 0u && (avail >= want || !any_step)) test_round(avail);
         else if (any_step) step(can_step);
     }
