@@ -86,6 +86,9 @@ struct pm_ctx {
     int nprims = 0, stride = 0;
     double yield[2] = {0.60, 0.36};   // stored photons per emission attempt (global, caustic): the reference scene's to begin with, then
                                       // what the last map of this scene showed (sizes the one emission range a map is made from)
+    double loose_tiles = 8.0;         // a pixel tile deeper than this many tile spans is not a gather group (PM_LOOSE_TILES; 0: every tile is one)
+    bool loose_auto = true;           // ... decided from the frame before: on when many tile groups were handed over as too spread out
+    bool loose_on = false;            //     (many small objects), off again when few tiles are that deep; PM_LOOSE_TILES set: always as told
     bool emit_stream = true;          // sphere grid: emission as a stream of attempts per wave (PM_EMIT_STREAM=0: one attempt per lane, for A/B runs)
     int emit_blocks = 512;            // blocks of k_emit_stream per launch: two maps side by side fill 256 CUs x 4 blocks (PM_EMIT_BLOCKS)
     bool shadow_queue = true;         // sphere grid: the rays of a wave share a queue of tests (PM_SHADOW_QUEUE=0: every ray tests on its own, for A/B runs)
@@ -96,7 +99,7 @@ struct pm_ctx {
     SceneView gv{};
     // frame work buffers (grow only, reused across frames)
     DevBuf geo, obj, pixel, node, tabslot, direct, radg, radc, color, clist, tab, ctr, pane, sample, sched, groups, left, strips;
-    DevBuf sp_keys_in, sp_keys_out, sp_vals_in, sp_vals_out, sp_sort_tmp, sp_bounds, sp_groups, sp_early, sp_pieces;   // spatial order of the bounced pixels' shade points
+    DevBuf sp_keys_in, sp_keys_out, sp_vals_in, sp_vals_out, sp_sort_tmp, sp_bounds, sp_groups, sp_early, sp_pieces, sp_loose;   // spatial order of the bounced pixels' shade points
     bool use_tiles = true;     // PM_GATHER_TILE=0: every shade point goes through the per-query kernel (A/B switch)
     double sp_cell = 6.0;      // cell size of those groups in 63-NN radii (PM_SP_CELL), and the shortest run worth a group (PM_SP_MIN_RUN)
     int sp_min_run = 16;
@@ -188,7 +191,7 @@ extern "C" int pm_ctx_destroy(pm_ctx *ctx) {
     if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
     DevBuf *bufs[] = {&ctx->scene, &ctx->sgrid, &ctx->geo, &ctx->obj, &ctx->pixel, &ctx->node, &ctx->tabslot, &ctx->direct, &ctx->radg, &ctx->radc,
                       &ctx->color, &ctx->clist, &ctx->tab, &ctx->ctr, &ctx->pane, &ctx->sample, &ctx->sched, &ctx->groups, &ctx->left, &ctx->strips,
-                      &ctx->sp_keys_in, &ctx->sp_keys_out, &ctx->sp_vals_in, &ctx->sp_vals_out, &ctx->sp_sort_tmp, &ctx->sp_bounds, &ctx->sp_groups, &ctx->sp_early, &ctx->sp_pieces};
+                      &ctx->sp_keys_in, &ctx->sp_keys_out, &ctx->sp_vals_in, &ctx->sp_vals_out, &ctx->sp_sort_tmp, &ctx->sp_bounds, &ctx->sp_groups, &ctx->sp_early, &ctx->sp_pieces, &ctx->sp_loose};
     for (DevBuf *b : bufs) b->release();
     for (pm_map *m : ctx->spare) free_map(m);
     ctx->spare.clear();
@@ -340,6 +343,7 @@ extern "C" int pm_scene_upload(pm_ctx *ctx, const pm_prim *prims, int32_t n) {
     ctx->nprims = n; ctx->stride = stride; ctx->scene_b = bytes;
     ctx->yield[0] = 0.60; ctx->yield[1] = 0.36;
     ctx->yield_known[0] = ctx->yield_known[1] = false;
+    ctx->loose_on = false;
     ctx->scene_mode = bytes <= LDS_SCENE_MAX ? SCENE_LDS : SCENE_GLOBAL;
     unsigned char *d = ctx->scene.as<unsigned char>();
     ctx->gv = SceneView{};
@@ -1020,6 +1024,7 @@ static int gather_blocks(pm_ctx *ctx) {
     if (const char *v = getenv("PM_SP_CELL")) { double x = atof(v); if (x > 0.1 && x < 100) ctx->sp_cell = x; }
     if (const char *v = getenv("PM_SP_EST")) { double x = atof(v); if (x > 0.01 && x < 1000) ctx->sp_est = x; }
     if (const char *v = getenv("PM_TILE_PARTS")) { int x = atoi(v); if (x >= 1 && x <= 4) ctx->tile_parts = x; }
+    if (const char *v = getenv("PM_LOOSE_TILES")) { double x = atof(v); if (x >= 0 && x < 1e6) { ctx->loose_tiles = x; ctx->loose_auto = false; } }
     if (const char *v = getenv("PM_SP_MIN_RUN")) { int x = atoi(v); if (x >= 1 && x <= 64) ctx->sp_min_run = x; }
     if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] resident gather blocks: group kernel %d (%d per CU), per-query kernel %d (%d per CU), %d CUs\n", ctx->tile_blocks, per_cu_t,
                                     ctx->query_blocks, per_cu_q, cus);
@@ -1058,8 +1063,16 @@ static int enqueue_frame(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
     HIPCHK(hipMemsetAsync(d_ctr, 0, sizeof(Counters), ctx->stream));
     const bool count_tests = (rp->flags & PM_FLAG_COUNT_TESTS) != 0;
-    if (count_tests) LAUNCH_SCENE(k_primary_count, grid_px, block, ctx, fp, d_pane, d_ctr, q, ctx->clist.as<uint32_t>(), ctx->groups.as<uint2>());
-    else LAUNCH_SCENE(k_primary, grid_px, block, ctx, fp, d_pane, d_ctr, q, ctx->clist.as<uint32_t>(), ctx->groups.as<uint2>());
+    // tiles spread out in depth are not groups: their points are sorted by where they lie, with the bounced pixels' points.
+    // A tile of 8 pixels spans 8 / (fov |cam.z|) of its distance; `loose_tiles` of those spans is as deep as a group may be.
+    const bool sort_bounced = ctx->use_tiles && ctx->group_bounced;
+    double loose_k = 0.0;
+    if (sort_bounced && ctx->loose_tiles > 0 && (ctx->loose_on || !ctx->loose_auto) && fp.cam.z != 0) {
+        const double span = 8.0 / ((fp.width / 1280.0) * 64.0 * fabs(fp.cam.z));
+        loose_k = (1.0 + ctx->loose_tiles * span) * (1.0 + ctx->loose_tiles * span);
+    }
+    if (count_tests) LAUNCH_SCENE(k_primary_count, grid_px, block, ctx, fp, d_pane, d_ctr, q, ctx->clist.as<uint32_t>(), ctx->groups.as<uint2>(), ctx->sp_loose.as<uint32_t>(), loose_k);
+    else LAUNCH_SCENE(k_primary, grid_px, block, ctx, fp, d_pane, d_ctr, q, ctx->clist.as<uint32_t>(), ctx->groups.as<uint2>(), ctx->sp_loose.as<uint32_t>(), loose_k);
     hipLaunchKernelGGL(k_mark_primary, dim3(1), dim3(64), 0, ctx->stream, d_ctr, q.cap);
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
     LAUNCH_SCENE(k_secondary, dim3(std::min<unsigned>((c_cap + 255) / 256, 4096u)), block, ctx, fp, d_ctr, q, ctx->clist.as<uint32_t>(), c_cap, tab);
@@ -1085,24 +1098,24 @@ static int enqueue_frame(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
     const int dbg = getenv("PM_DEBUG") ? 1 : 0;
     // The shade points of bounced pixels (slots n_sp0 .. n_sp0 + n_bounced) in spatial order, for the group kernel; queued
     // before the wait for the maps, whose builds this overlaps.
-    const bool sort_bounced = use_tiles && ctx->group_bounced;
     if (sort_bounced) {
         HIPCHK(hipMemsetAsync(ctx->sp_bounds.p, 0xFF, 12, ctx->stream));                                   // minima
         HIPCHK(hipMemsetAsync(ctx->sp_bounds.as<unsigned char>() + 12, 0, 12, ctx->stream));             // maxima
-        hipLaunchKernelGGL(k_sp_bounds, dim3(std::min(256u, (b_cap + 255) / 256)), block, 0, ctx->stream, q, d_ctr, ctx->sp_bounds.as<uint32_t>());
-        hipLaunchKernelGGL(k_sp_morton, dim3((b_cap + 255) / 256), block, 0, ctx->stream, q, d_ctr, ctx->sp_bounds.as<uint32_t>(),
+        hipLaunchKernelGGL(k_sp_bounds, dim3(std::min(256u, (b_cap + 255) / 256)), block, 0, ctx->stream, q, d_ctr, ctx->sp_loose.as<uint32_t>(), ctx->sp_bounds.as<uint32_t>());
+        hipLaunchKernelGGL(k_sp_morton, dim3((b_cap + 255) / 256), block, 0, ctx->stream, q, d_ctr, ctx->sp_loose.as<uint32_t>(), ctx->sp_bounds.as<uint32_t>(),
                            ctx->sp_keys_in.as<uint64_t>(), ctx->sp_vals_in.as<uint32_t>());
         HIPCHK(radix_sort_pairs_30(ctx->stream, ctx->sp_keys_in.as<uint64_t>(), ctx->sp_vals_in.as<uint32_t>(), ctx->sp_keys_out.as<uint64_t>(),
-                                   ctx->sp_vals_out.as<uint32_t>(), ctx->sp_sort_tmp.as<uint32_t>(), b_cap, &d_ctr->n_bounced));
+                                   ctx->sp_vals_out.as<uint32_t>(), ctx->sp_sort_tmp.as<uint32_t>(), b_cap, &d_ctr->n_sorted));
         // cells of about six 63-NN radii (measured best on the default scene; most runs are then left to the tile kernel's own
         // test of how far a group is spread): r^2 = 63 / (pi * density), density = photons / surface, surface taken as that
         // of a cube over the points' extent (the sparser of the two maps decides)
         long long n_ph = std::max<long long>(1, std::min(gmap ? gmap->n : (1LL << 40), cmap ? cmap->n : (1LL << 40)));
         double cell_rel = ctx->sp_cell * sqrt(63.0 * 6.0 / (3.14159265 * (double)n_ph));
         hipLaunchKernelGGL(k_sp_pieces, dim3((b_cap + 255) / 256), block, 0, ctx->stream, ctx->sp_keys_out.as<uint64_t>(), cell_rel, ctx->sp_pieces.as<uint2>(), d_ctr);
-        // one wave per piece
+        // one wave per piece (a scene of many small objects has more surface than the cube over its points, which the estimate
+        // of the photon density assumes: twice the expected set is allowed there; measured 8.55 -> 8.3 ms on 10 000 spheres)
         hipLaunchKernelGGL(k_sp_classify, dim3(std::min<unsigned>((b_cap + 3) / 4, 1024u)), block, 0, ctx->stream, q, ctx->sp_vals_out.as<uint32_t>(), ctx->sp_pieces.as<uint2>(),
-                           ctx->sp_bounds.as<uint32_t>(), (double)n_ph / 6.0, ctx->sp_est * (double)PM_TILE_EST_MAX, (uint32_t)ctx->sp_min_run,
+                           ctx->sp_bounds.as<uint32_t>(), (double)n_ph / 6.0, ctx->sp_est * (loose_k > 0 && ctx->loose_auto ? 2.0 : 1.0) * (double)PM_TILE_EST_MAX, (uint32_t)ctx->sp_min_run,
                            ctx->sp_groups.as<uint2>(), d_ctr, ctx->sp_early.as<uint32_t>());
         HIPCHK(hipGetLastError());
     }
@@ -1224,6 +1237,7 @@ static int render_impl(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_
     for (int attempt = 0;; attempt++) {
         PMCHK(ensure_sp(ctx, want_sp));
         PMCHK(ctx->left.ensure((size_t)8 * ctx->sp_cap * 4 + 8));   // per map and part of the group launches
+        PMCHK(ctx->sp_loose.ensure((size_t)ctx->sp_cap * 4));
         if (want_c > ctx->c_cap) { PMCHK(ctx->tab.ensure((size_t)want_c * 16 * sizeof(NodeEntry))); ctx->c_cap = want_c; }
         if (want_b > ctx->b_cap) {
             PMCHK(ctx->sp_keys_in.ensure((size_t)want_b * 8)); PMCHK(ctx->sp_keys_out.ensure((size_t)want_b * 8));
@@ -1244,7 +1258,7 @@ static int render_impl(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_
             // the counters kept counting past the capacities: they say what the frame needs
             if (hc.overflow & OVF_SP) want_sp = std::max(want_sp, hc.n_sp);
             if (hc.overflow & OVF_COMPLEX) { want_c = hc.n_complex + hc.n_complex / 8; want_sp = std::max<uint64_t>(want_sp, std::min<uint64_t>((uint64_t)hc.n_sp + 15ull * (hc.n_complex - ctx->c_cap), 0xFFFFFF00u)); }
-            if (hc.overflow & OVF_BOUNCED) want_b = (hc.n_sp - hc.n_sp0) + (hc.n_sp - hc.n_sp0) / 8;
+            if (hc.overflow & OVF_BOUNCED) { const uint32_t need = (hc.n_sp - hc.n_sp0) + hc.n_loose; want_b = need + need / 8; }
             again = true;
         }
         // the maps the streams waited for: did their one emission range hold n photons?  (a scene that stores far fewer photons
@@ -1269,6 +1283,13 @@ static int render_impl(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
     const Counters hc = *ctx->h_ctr;
+    if (ctx->loose_auto && ctx->use_tiles && hc.n_sp0 > 0) {
+        // the next frame of this scene: tiles that are deep go through the spatial sort when this frame handed a good part of its
+        // shade points over to the per-query kernel (groups too spread out for one shared set, mostly; both maps counted)
+        const int n_maps = (gathered[0] ? 1 : 0) + (gathered[1] ? 1 : 0);
+        if (!ctx->loose_on) ctx->loose_on = n_maps > 0 && (double)left_of(hc, 0) + (double)left_of(hc, 1) > 0.15 * n_maps * (double)hc.n_sp0;
+        else ctx->loose_on = (double)hc.n_loose > 0.05 * (double)hc.n_sp0;
+    }
     const uint32_t n_sp0 = hc.n_sp0, n_sp = hc.n_sp0 + hc.n_bounced, n_complex = hc.n_complex, n_secondary = hc.n_secondary;
     const bool sort_bounced = ctx->use_tiles && ctx->group_bounced;
     const uint32_t n_sorted = sort_bounced ? hc.n_bounced : 0u, n_primary_sp = ctx->use_tiles ? n_sp0 + n_sorted : 0u;
@@ -1277,7 +1298,8 @@ static int render_impl(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_
     if (getenv("PM_DEBUG")) {
         fprintf(stderr, "[pm] shade points %u (primary %u), groups %u, left to the per-query gather: global %u caustic %u\n", n_sp, n_sp0,
                 hc.n_groups, left_of(hc, 0), left_of(hc, 1));
-        fprintf(stderr, "[pm] bounced pixels' shade points in spatial order: %u, in %u groups; %u straight to the per-query kernel\n", n_sorted, hc.n_sgroups, hc.n_early);
+        fprintf(stderr, "[pm] shade points in spatial order: %u of bounced pixels + %u of spread-out tiles, in %u groups; %u straight to the per-query kernel\n", n_sorted,
+                hc.n_sorted - hc.n_bounced, hc.n_sgroups, hc.n_early);
         fprintf(stderr, "[pm] lanes handed over, by reason (few photons, spread, radius, |S|, no lane served, -, own shortfall): %u %u %u %u %u %u %u\n", hc.why[1], hc.why[2],
                 hc.why[3], hc.why[4], hc.why[5], hc.why[6], hc.why[7]);
         for (int k = 0; k < 2; k++) {

@@ -31,7 +31,7 @@ struct FrameParams {
     int rank, world;
 };
 
-struct Counters { uint32_t n_sp, n_complex, n_secondary, n_groups, n_left[2][4], pad, n_sgroups, n_early, n_pieces, overflow, n_sp0, n_bounced, done_primary, done_secondary; unsigned long long tests[4]; unsigned long long walk[4]; uint32_t why[8]; unsigned long long tphase[8]; uint32_t ghist[2][32]; };   // n_left[k][p]: shade points that part p of map k's group launches left to the per-query gather
+struct Counters { uint32_t n_sp, n_complex, n_secondary, n_groups, n_left[2][4], pad, n_sgroups, n_early, n_pieces, overflow, n_sp0, n_bounced, done_primary, done_secondary, n_loose, n_sorted; unsigned long long tests[4]; unsigned long long walk[4]; uint32_t why[8]; unsigned long long tphase[8]; uint32_t ghist[2][32]; };   // n_left[k][p]: shade points that part p of map k's group launches left to the per-query gather
 
 // The frame's counts live on the device: nothing of a frame waits for the host.  n_sp0 = shade points of primary hits (slots
 // 0 .. n_sp0, grouped by pixel tile), written by k_mark_primary behind k_primary; n_bounced = shade points of bounced pixels
@@ -39,6 +39,8 @@ struct Counters { uint32_t n_sp, n_complex, n_secondary, n_groups, n_left[2][4],
 // capacity of the queues and reads what there really is from here.  overflow: bit 0 = a shade point did not fit, bit 1 = more
 // bounced pixels than node tables, bit 2 = more bounced pixels' shade points than the spatial sort was sized for; the host
 // looks at it once, when the frame is over, grows what was too small and renders the frame again.
+// n_loose: shade points of primary hits whose pixel tile is spread out in depth (k_primary lists their slots instead of making
+// the tile a group); n_sorted = n_bounced + n_loose: what goes through the spatial sort.
 enum { OVF_SP = 1u, OVF_COMPLEX = 2u, OVF_BOUNCED = 4u };
 __device__ inline uint32_t sp_total(const Counters *ctr, uint32_t cap) { return min(ctr->n_sp0 + ctr->n_bounced, cap); }
 // (A counter of finished blocks would let the last block of k_primary write n_sp0 itself, but 8 100 blocks adding to one
@@ -102,8 +104,12 @@ __device__ inline void wave_add_count(unsigned long long *to, uint32_t mine) {
     for (int s = 1; s < 64; s <<= 1) v += (uint32_t)__shfl_xor((int)v, s);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(to, (unsigned long long)v);
 }
+// loose_k > 0: a tile whose shade points lie at squared distances from the camera further apart than this factor is no group
+// of neighbours (a sphere in front of a wall, several small spheres one behind the other): its points are listed in `loose`
+// and grouped with the bounced pixels' points by where they lie, not by the pixel they are seen through.
 template <int MODE, bool COUNT>
-__device__ inline void primary_body(const SceneView &gs, const FrameParams &fp, uint32_t *pane, Counters *ctr, const SPQueue &q, uint32_t *complex_list, uint2 *groups) {
+__device__ inline void primary_body(const SceneView &gs, const FrameParams &fp, uint32_t *pane, Counters *ctr, const SPQueue &q, uint32_t *complex_list, uint2 *groups,
+                                    uint32_t *loose, double loose_k) {
     extern __shared__ __align__(16) unsigned char smem[];
     TestCount tc = {0u, 0u, 0u, 0u, 0u};
     SceneView sv = gs;
@@ -130,13 +136,22 @@ __device__ inline void primary_body(const SceneView &gs, const FrameParams &fp, 
     unsigned long long m = __ballot(emit_sp);
     if (m) {
         int leader = __ffsll((long long)m) - 1;
-        uint32_t base = 0;
+        bool spread = false;
+        if (loose_k > 0) {
+            const double d2 = (res.x - fp.cam.x) * (res.x - fp.cam.x) + (res.y - fp.cam.y) * (res.y - fp.cam.y) + (res.z - fp.cam.z) * (res.z - fp.cam.z);
+            const double near2 = wave_min_f64(emit_sp ? d2 : 1e300), far2 = wave_max_f64(emit_sp ? d2 : 0.0);
+            spread = far2 > near2 * loose_k;
+        }
+        uint32_t base = 0, lbase = 0;
         if (lane == leader) {
             base = atomicAdd(&ctr->n_sp, (uint32_t)__popcll(m));
-            groups[atomicAdd(&ctr->n_groups, 1u)] = make_uint2(base, (uint32_t)__popcll(m));   // the tile's shade points: one gather group
+            if (spread) lbase = atomicAdd(&ctr->n_loose, (uint32_t)__popcll(m));
+            else groups[atomicAdd(&ctr->n_groups, 1u)] = make_uint2(base, (uint32_t)__popcll(m));   // the tile's shade points: one gather group
         }
-        base = __shfl(base, leader);
-        if (emit_sp) sp_store(q, base + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL)), res, nrm, obj, pixel, 1u, 0u);
+        base = __shfl(base, leader); lbase = __shfl(lbase, leader);
+        const uint32_t rank = (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL));
+        if (emit_sp) sp_store(q, base + rank, res, nrm, obj, pixel, 1u, 0u);
+        if (emit_sp && spread && lbase + rank < q.cap) loose[lbase + rank] = base + rank;
     }
     m = __ballot(emit_cx);
     if (m) {
@@ -149,13 +164,13 @@ __device__ inline void primary_body(const SceneView &gs, const FrameParams &fp, 
     if (COUNT) { wave_add_count(&ctr->tests[0], tc.spheres); wave_add_count(&ctr->tests[1], tc.planes); }
 }
 template <int MODE>
-__global__ __launch_bounds__(256) void k_primary(SceneView gs, FrameParams fp, uint32_t *pane, Counters *ctr, SPQueue q, uint32_t *complex_list, uint2 *groups) {
-    primary_body<MODE, false>(gs, fp, pane, ctr, q, complex_list, groups);
+__global__ __launch_bounds__(256) void k_primary(SceneView gs, FrameParams fp, uint32_t *pane, Counters *ctr, SPQueue q, uint32_t *complex_list, uint2 *groups, uint32_t *loose, double loose_k) {
+    primary_body<MODE, false>(gs, fp, pane, ctr, q, complex_list, groups, loose, loose_k);
 }
 // the same pass counting the primitive tests it makes (PM_FLAG_COUNT_TESTS: the bench's intersection roofline; never the timed frame)
 template <int MODE>
-__global__ __launch_bounds__(256) void k_primary_count(SceneView gs, FrameParams fp, uint32_t *pane, Counters *ctr, SPQueue q, uint32_t *complex_list, uint2 *groups) {
-    primary_body<MODE, true>(gs, fp, pane, ctr, q, complex_list, groups);
+__global__ __launch_bounds__(256) void k_primary_count(SceneView gs, FrameParams fp, uint32_t *pane, Counters *ctr, SPQueue q, uint32_t *complex_list, uint2 *groups, uint32_t *loose, double loose_k) {
+    primary_body<MODE, true>(gs, fp, pane, ctr, q, complex_list, groups, loose, loose_k);
 }
 // the counts of the pass that just ended, for the kernels behind it (one thread)
 __global__ void k_mark_primary(Counters *ctr, uint32_t cap) {
@@ -163,9 +178,10 @@ __global__ void k_mark_primary(Counters *ctr, uint32_t cap) {
 }
 __global__ void k_mark_secondary(Counters *ctr, uint32_t cap, uint32_t b_cap) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const uint32_t total = min(ctr->n_sp, cap), nb = total - ctr->n_sp0;
-    if (nb > b_cap) atomicOr(&ctr->overflow, (uint32_t)OVF_BOUNCED);
+    const uint32_t total = min(ctr->n_sp, cap), nb = total - ctr->n_sp0, nl = min(ctr->n_loose, cap);
+    if ((unsigned long long)nb + nl > b_cap) atomicOr(&ctr->overflow, (uint32_t)OVF_BOUNCED);
     ctr->n_bounced = min(nb, b_cap);     // what the kernels behind may touch; the flag has the frame rendered again
+    ctr->n_sorted = ctr->n_bounced + min(nl, b_cap - ctr->n_bounced);
 }
 
 // hit ids / points / normals only (parity gate for primary rays)
@@ -319,15 +335,21 @@ __global__ __launch_bounds__(256) void k_shadow(SceneView gs, FrameParams fp, SP
 // ones are neighbours on some surface and are gathered as a group like the shade points of a pixel tile.
 __device__ inline uint32_t sp_f2ord(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ inline float sp_ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
-__global__ __launch_bounds__(256) void k_sp_bounds(SPQueue q, const Counters *ctr, uint32_t *bounds) {
+// slot of the i-th shade point that is sorted: the bounced pixels' points first, then the listed points of spread-out tiles
+__device__ inline uint32_t sp_sorted_slot(const Counters *ctr, const uint32_t *loose, uint32_t i) {
+    return i < ctr->n_bounced ? ctr->n_sp0 + i : loose[i - ctr->n_bounced];
+}
+__global__ __launch_bounds__(256) void k_sp_bounds(SPQueue q, const Counters *ctr, const uint32_t *loose, uint32_t *bounds) {
     __shared__ uint32_t part[4][6];
-    const uint32_t lo = ctr->n_sp0, n = ctr->n_bounced;
+    const uint32_t n = ctr->n_sorted;
     uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0, 0, 0};
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t slot = sp_sorted_slot(ctr, loose, i);
         for (int a = 0; a < 3; a++) {
-            uint32_t v = sp_f2ord((float)q.geo[a * (size_t)q.cap + lo + i]);
+            uint32_t v = sp_f2ord((float)q.geo[a * (size_t)q.cap + slot]);
             mn[a] = min(mn[a], v); mx[a] = max(mx[a], v);
         }
+    }
     for (int a = 0; a < 3; a++) {
         for (int s = 1; s < 64; s <<= 1) { mn[a] = min(mn[a], (uint32_t)__shfl_xor((int)mn[a], s)); mx[a] = max(mx[a], (uint32_t)__shfl_xor((int)mx[a], s)); }
         if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][a] = mn[a]; part[threadIdx.x >> 6][3 + a] = mx[a]; }
@@ -339,16 +361,17 @@ __global__ __launch_bounds__(256) void k_sp_bounds(SPQueue q, const Counters *ct
         if (threadIdx.x < 3) atomicMin(&bounds[threadIdx.x], v); else atomicMax(&bounds[threadIdx.x], v);
     }
 }
-__global__ __launch_bounds__(256) void k_sp_morton(SPQueue q, const Counters *ctr, const uint32_t *bounds, uint64_t *keys, uint32_t *vals) {
-    const uint32_t lo = ctr->n_sp0, n = ctr->n_bounced;
+__global__ __launch_bounds__(256) void k_sp_morton(SPQueue q, const Counters *ctr, const uint32_t *loose, const uint32_t *bounds, uint64_t *keys, uint32_t *vals) {
+    const uint32_t n = ctr->n_sorted;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const uint32_t slot = sp_sorted_slot(ctr, loose, i);
     float ext = 0.f;
     for (int a = 0; a < 3; a++) ext = fmaxf(ext, sp_ord2f(bounds[3 + a]) - sp_ord2f(bounds[a]));
     uint32_t qv[3];
-    for (int a = 0; a < 3; a++) qv[a] = quant21((float)q.geo[a * (size_t)q.cap + lo + i], sp_ord2f(bounds[a]), ext);
+    for (int a = 0; a < 3; a++) qv[a] = quant21((float)q.geo[a * (size_t)q.cap + slot], sp_ord2f(bounds[a]), ext);
     keys[i] = morton63(qv[0], qv[1], qv[2]);
-    vals[i] = lo + i;
+    vals[i] = slot;
 }
 
 // Groups of the sorted shade points.  k_sp_pieces: the runs that share an octree cell of about `cell_rel` times the extent
@@ -358,7 +381,7 @@ __global__ __launch_bounds__(256) void k_sp_morton(SPQueue q, const Counters *ct
 // photon density in place of a centre query) within `est_max`.  The others go to the `early` list: the per-query kernel
 // takes them on a stream of its own right away, beside the group kernels, instead of after them.
 __global__ __launch_bounds__(256) void k_sp_pieces(const uint64_t *keys, double cell_rel, uint2 *pieces, Counters *ctr) {
-    const uint32_t n = ctr->n_bounced;
+    const uint32_t n = ctr->n_sorted;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int level = 1;

@@ -70,6 +70,39 @@ def test_c5_pane_bit_exact(c5, orc):
     g.destroy(); c.destroy(); og.close(); oc.close()
 
 
+@pytest.mark.parametrize("loose", ["0", "2", "8"])
+def test_c5_spread_out_tiles_through_the_spatial_sort(orc, loose, monkeypatch):
+    """Pixel tiles that are deep (several small spheres one behind the other) are not gather groups: their shade points are
+    sorted by where they lie and grouped with the bounced pixels' points (PM_LOOSE_TILES: how deep, in tile spans; 0: never;
+    unset: decided from the frame before).  Whatever the routing, the pane is the oracle's."""
+    import raytracer_amd as ra
+    monkeypatch.setenv("PM_LOOSE_TILES", loose)
+    scene = ra.many_spheres_scene()
+    ctx = _ctx(scene)
+    try:
+        w, h, n, seed = 192, 128, 20000, 43
+        g, c = ctx.create_map(0, n, seed), ctx.create_map(1, n, seed)
+        pane, st = ctx.render(g, c, ctx.params(w, h, seed))
+        og, oc = orc.Map(g.download()), orc.Map(c.download())
+        want, ost = orc.render(scene, og, oc, orc.params(w, h, seed), nthreads=16)
+        assert np.array_equal(pane, want)
+        assert st.gathers == ost.gathers
+        g.destroy(); c.destroy(); og.close(); oc.close()
+    finally:
+        ctx.close()
+
+
+def test_c5_frames_in_a_row_agree(c5):
+    """The routing of spread-out tiles is decided from the frame before: the first, second and third frame of a scene
+    (routing off, on, on) give the same pane."""
+    ctx, scene = c5
+    w, h, n, seed = 480, 320, 100000, 44
+    g, c = ctx.create_map(0, n, seed), ctx.create_map(1, n, seed)
+    panes = [ctx.render(g, c, ctx.params(w, h, seed))[0].copy() for _ in range(3)]
+    assert np.array_equal(panes[0], panes[1]) and np.array_equal(panes[0], panes[2])
+    g.destroy(); c.destroy()
+
+
 def test_c5_grid_equals_linear_scan_at_size(c5):
     """720 x 720, 200 000 photons per map: hits, photons and pane with the grid = those of the linear scan on the GPU."""
     ctx, scene = c5
