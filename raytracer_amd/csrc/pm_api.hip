@@ -1309,6 +1309,9 @@ static int render_impl(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_
         }
         fprintf(stderr, "[pm] group kernel ticks per phase (centre query, collect, pass 1, pass 2, rank, sum): %llu %llu %llu %llu %llu %llu; shared sets %llu, candidates %llu\n", hc.tphase[0],
                 hc.tphase[1], hc.tphase[2], hc.tphase[3], hc.tphase[4], hc.tphase[5], hc.tphase[7], hc.tphase[6]);
+#ifdef PM_PAIR_STATS
+        fprintf(stderr, "[pm] per-query gathers answered by the half-wave block query: global %u of %u, caustic %u of %u\n", hc.ghist[0][1], hc.ghist[0][0], hc.ghist[1][1], hc.ghist[1][0]);
+#endif
         if (hc.walk[0]) fprintf(stderr, "[pm] shadow pass through the sphere grid: %llu sphere tests, %llu cells entered by %u rays; the waves made %llu steps and %llu rounds of tests\n",
                                 hc.tests[2], hc.walk[0], 25u * n_sp, hc.walk[1], hc.walk[2]);
     }

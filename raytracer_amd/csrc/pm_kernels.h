@@ -604,6 +604,9 @@ __global__ __launch_bounds__(256) void k_gather_pair(MapView m_in, SPQueue q, co
         double R, G, B;
         const bool ok = pair_gather<KIND>(&buf->pair, m, p, nrm, have, R, G, B);
         if (ok && (lane & 31) == 0) { out[0 * (size_t)q.cap + s] = R; out[1 * (size_t)q.cap + s] = G; out[2 * (size_t)q.cap + s] = B; }
+#ifdef PM_PAIR_STATS
+        if ((lane & 31) == 0 && have) { atomicAdd(const_cast<uint32_t *>(&ctr->ghist[KIND][0]), 1u); if (ok) atomicAdd(const_cast<uint32_t *>(&ctr->ghist[KIND][1]), 1u); }
+#endif
         // what a half could not answer: the whole wave, with the walk
         unsigned long long todo = __ballot(have && !ok && (lane & 31) == 0);
         while (todo) {
