@@ -23,6 +23,7 @@
 // ray, which change neither a minimum over all of the ray's hits nor an OR.
 #pragma once
 #include "pm_device.h"
+#include "pm_knn.h"
 
 namespace pm {
 
@@ -214,19 +215,32 @@ struct WaveTracer {
 
     // one action of the wave
     __device__ void pump() {
-        for (;;) {      // queue: one reference per lane and turn, lanes in order
-            const bool has = walking && r < e;
-            const unsigned long long m = __ballot(has);
-            if (!m) break;
-            const uint32_t n = (uint32_t)__popcll(m);
-            if (tail - head + n > (uint32_t)TQ_CAP) break;
-            TRACE_STAT(7, 1);
-            if (has) {
-                const uint32_t at = (tail + (uint32_t)__popcll(m & below)) & (TQ_CAP - 1);
-                wb.qref[at] = r; wb.qsrc[at] = (unsigned char)lane;
-                r++;
+        // queue the references of the cells just entered: every lane its own run of slots behind the tail (a prefix sum over
+        // the lanes' counts), or, when the ring cannot take them all, one reference per lane and turn as far as it goes
+        const uint32_t cnt = walking ? e - r : 0u;
+        if (__ballot(cnt != 0u)) {
+            const uint32_t incl = wave_scan_incl_u32(cnt);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (tail - head + total <= (uint32_t)TQ_CAP) {
+                uint32_t at = tail + incl - cnt;
+                for (uint32_t k = r; k < e; k++, at++) { wb.qref[at & (TQ_CAP - 1)] = k; wb.qsrc[at & (TQ_CAP - 1)] = (unsigned char)lane; }
+                r = e;
+                tail += total;
+            } else {
+                for (;;) {
+                    const bool has = walking && r < e;
+                    const unsigned long long m = __ballot(has);
+                    if (!m) break;
+                    const uint32_t n = (uint32_t)__popcll(m);
+                    if (tail - head + n > (uint32_t)TQ_CAP) break;
+                    if (has) {
+                        const uint32_t at = (tail + (uint32_t)__popcll(m & below)) & (TQ_CAP - 1);
+                        wb.qref[at] = r; wb.qsrc[at] = (unsigned char)lane;
+                        r++;
+                    }
+                    tail += n;
+                }
             }
-            tail += n;
         }
         const bool can_step = walking && r >= e;
         const bool any_step = __ballot(can_step) != 0ULL;
