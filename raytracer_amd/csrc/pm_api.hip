@@ -450,6 +450,14 @@ static int emit_range(pm_ctx *ctx, BuildSlot &sl, int kind, uint64_t seed, const
     return emit_range_on(ctx, sl.stream, es, kind, seed, lc, a0, count, d_out, cap, h_got, total, d_running, bounds_init);
 }
 
+#ifdef PM_PAIR_STAMPS
+extern "C" int pm_pair_ticks(unsigned long long *out8, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_pair_ticks), 8 * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pair_ticks), z, 8 * 8) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 #ifdef PM_TRACE_STATS
 extern "C" int pm_trace_stats(unsigned long long *out16, int reset) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;

@@ -603,6 +603,9 @@ __global__ __launch_bounds__(256) void k_gather_pair(MapView m_in, SPQueue q, co
         const V3 nrm = {q.geo[3 * (size_t)q.cap + s], q.geo[4 * (size_t)q.cap + s], q.geo[5 * (size_t)q.cap + s]};
         double R, G, B;
         const bool ok = pair_gather<KIND>(&buf->pair, m, p, nrm, have, R, G, B);
+#ifdef PM_PAIR_STAMPS
+        if (lane == 0) atomicAdd(&g_pair_ticks[7], 1ULL);
+#endif
         if (ok && (lane & 31) == 0) { out[0 * (size_t)q.cap + s] = R; out[1 * (size_t)q.cap + s] = G; out[2 * (size_t)q.cap + s] = B; }
 #ifdef PM_PAIR_STATS
         if ((lane & 31) == 0 && have) { atomicAdd(const_cast<uint32_t *>(&ctr->ghist[KIND][0]), 1u); if (ok) atomicAdd(const_cast<uint32_t *>(&ctr->ghist[KIND][1]), 1u); }
@@ -618,7 +621,13 @@ __global__ __launch_bounds__(256) void k_gather_pair(MapView m_in, SPQueue q, co
             carry.full = false;
             double R2, G2, B2;
             wave_lds_fence();
+#ifdef PM_PAIR_STAMPS
+            const unsigned long long tw0_ = __builtin_amdgcn_s_memtime();
+#endif
             knn_gather<KIND>(&buf->knn, m, p2, n2, R2, G2, B2, carry);
+#ifdef PM_PAIR_STAMPS
+            if (lane == 0) { atomicAdd(&g_pair_ticks[5], __builtin_amdgcn_s_memtime() - tw0_); atomicAdd(&g_pair_ticks[6], 1ULL); }
+#endif
             if (lane == 0) { out[0 * (size_t)q.cap + s2] = R2; out[1 * (size_t)q.cap + s2] = G2; out[2 * (size_t)q.cap + s2] = B2; }
             wave_lds_fence();
         }

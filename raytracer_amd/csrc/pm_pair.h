@@ -16,6 +16,10 @@ namespace pm {
 
 constexpr int PAIR_BUF = 160;                  // candidates a half-wave buffers before it selects (5 slots of 32)
 constexpr int PAIR_SLOTS = PAIR_BUF / 32;
+#ifndef PM_PAIR_AHEAD
+#define PM_PAIR_AHEAD 1
+#endif
+constexpr int PAIR_AHEAD = PM_PAIR_AHEAD;          // rounds of the block scan fetched together
 
 struct PairHalf {
     unsigned long long d[PAIR_BUF];            // squared distances as IEEE bit patterns
@@ -26,6 +30,16 @@ struct PairHalf {
     unsigned long long acc[4];
 };
 struct PairBuf { PairHalf h[2]; };
+
+#ifdef PM_PAIR_STAMPS
+// diagnostics (builds with -DPM_PAIR_STAMPS only): clock ticks of a wave per phase of pair_gather, summed over all waves
+static __device__ unsigned long long g_pair_ticks[8];
+#define PAIR_LAP(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) atomicAdd(&g_pair_ticks[k], now_ - ts_); ts_ = now_; }
+#define PAIR_T0 unsigned long long ts_ = __builtin_amdgcn_s_memtime();
+#else
+#define PAIR_LAP(k)
+#define PAIR_T0
+#endif
 
 // this lane's half of a 64-bit ballot
 __device__ inline uint32_t half_mask(unsigned long long m, int half) { return half ? (uint32_t)(m >> 32) : (uint32_t)m; }
@@ -120,6 +134,7 @@ __device__ inline bool pair_gather(PairBuf *pb, const MapView &m, const V3 &q, c
     const int lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
     PairHalf *hb = &pb->h[half];
     R = G = B = 0.0;
+    PAIR_T0
     const int L = m.lmax;
     bool ok = have && m.n >= KNN_K && L >= 1;
     const double qa[3] = {q.x, q.y, q.z};
@@ -146,6 +161,7 @@ __device__ inline bool pair_gather(PairBuf *pb, const MapView &m, const V3 &q, c
     mdist -= 3.0 * m.gu;
     ok = ok && mdist > 0.0;
     double lim = fmin(mdist * mdist, MAX_R2);
+    PAIR_LAP(0)
     // the block's cells, one per lane of the half
     first = 0; cnt = 0;
     if (ok && hl < 27) {
@@ -171,38 +187,57 @@ __device__ inline bool pair_gather(PairBuf *pb, const MapView &m, const V3 &q, c
         if (cnt > 0) { hb->pre[k] = incl; hb->off[k] = first - (incl - cnt); }
     }
     wave_lds_fence();
+    PAIR_LAP(1)
     int count = 0;
     const uint32_t below = (1u << hl) - 1u;
     const uint32_t longest = max((uint32_t)__builtin_amdgcn_readlane((int)total, 0), (uint32_t)__builtin_amdgcn_readlane((int)total, 32));
-    for (uint32_t base = 0; base < longest; base += 32) {
-        const uint32_t t = base + (uint32_t)hl;
-        int j = 0;
+    // PAIR_AHEAD rounds of 32 photons are looked up and fetched together, then taken in turn.  (The scan is 58 % of a wave's
+    // time in this function and it is waiting for memory -- tools/pair_phases.py -- but 2 or 4 rounds in flight changed no
+    // step time: the gather phase is bound by the device's vector issue, which a wave that waits does not use.  1 = no look-ahead.)
+    for (uint32_t base = 0; base < longest; base += 32 * PAIR_AHEAD) {
+        uint32_t ia[PAIR_AHEAD];
+        float4 pa[PAIR_AHEAD];
 #pragma unroll
-        for (int step = 16; step > 0; step >>= 1)
-            if (hb->pre[j + step - 1] <= t) j += step;
-        const bool valid = t < total;
-        const uint32_t i = valid ? hb->off[j] + t : 0u;
-        const float4 p = valid ? m.pos4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const double ddx = (double)p.x - q.x, ddy = (double)p.y - q.y, ddz = (double)p.z - q.z;   // src/PhotonMap.cpp:211-214
-        const double d2 = ddx * ddx + ddy * ddy + ddz * ddz;
-        const bool pass = valid && d2 < lim;
-        const uint32_t mh = half_mask(__ballot(pass), half);
-        if (pass) {
-            const int pos = count + __popc(mh & below);
-            hb->d[pos] = (unsigned long long)__double_as_longlong(d2);
-            hb->i[pos] = i;
+        for (int u = 0; u < PAIR_AHEAD; u++) {
+            const uint32_t t = base + 32u * (uint32_t)u + (uint32_t)hl;
+            int j = 0;
+#pragma unroll
+            for (int step = 16; step > 0; step >>= 1)
+                if (hb->pre[j + step - 1] <= t) j += step;
+            const bool valid = t < total;
+            ia[u] = valid ? hb->off[j] + t : 0u;
+            pa[u] = valid ? m.pos4[ia[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        count += __popc(mh);
-        // a half whose buffer could not take another round selects now (its bound falls to the 63rd distance so far)
-        const bool full = count > PAIR_BUF - 32;
-        if (__ballot(full)) {
-            wave_lds_fence();
-            const unsigned long long tau = pair_reduce(hb, half, hl, full, count, lim, ok);
-            if (full) { count = KNN_K; lim = __longlong_as_double((long long)tau); }
-            if (!ok) { total = 0; }          // (gives up: nothing more is read for this half)
+#pragma unroll
+        for (int u = 0; u < PAIR_AHEAD; u++) {
+            const uint32_t t = base + 32u * (uint32_t)u + (uint32_t)hl;
+            const bool valid = t < total;                    // (total is 0 for a half that has given up meanwhile)
+            const uint32_t i = ia[u];
+            const float4 p = pa[u];
+            const double ddx = (double)p.x - q.x, ddy = (double)p.y - q.y, ddz = (double)p.z - q.z;   // src/PhotonMap.cpp:211-214
+            const double d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+            const bool pass = valid && d2 < lim;
+            const uint32_t mh = half_mask(__ballot(pass), half);
+            if (pass) {
+                const int pos = count + __popc(mh & below);
+                hb->d[pos] = (unsigned long long)__double_as_longlong(d2);
+                hb->i[pos] = i;
+            }
+            count += __popc(mh);
+            // a half whose buffer could not take another round selects now (its bound falls to the 63rd distance so far)
+            const bool full = count > PAIR_BUF - 32;
+            if (__ballot(full)) {
+                wave_lds_fence();
+                PAIR_LAP(2)
+                const unsigned long long tau = pair_reduce(hb, half, hl, full, count, lim, ok);
+                PAIR_LAP(3)
+                if (full) { count = KNN_K; lim = __longlong_as_double((long long)tau); }
+                if (!ok) { total = 0; }          // (gives up: nothing more is read for this half)
+            }
         }
     }
     wave_lds_fence();
+    PAIR_LAP(2)
     ok = ok && count >= KNN_K;
     {
         const bool sel = ok;                  // (every answered query selects once more: the buffer holds >= 63 candidates below lim)
@@ -211,6 +246,7 @@ __device__ inline bool pair_gather(PairBuf *pb, const MapView &m, const V3 &q, c
             if (sel) { count = KNN_K; lim = __longlong_as_double((long long)tau); }
         }
     }
+    PAIR_LAP(3)
     if (__ballot(ok) == 0ULL) return false;
     // radiance: the half's 63 entries, two per lane, summed in 64-bit fixed point (canonical order-independent sum)
     const double r = lim;
@@ -240,6 +276,7 @@ __device__ inline bool pair_gather(PairBuf *pb, const MapView &m, const V3 &q, c
     G = ((double)(long long)hb->acc[1] * (1.0 / FX_SCALE)) / (norm_k * r);
     B = ((double)(long long)hb->acc[2] * (1.0 / FX_SCALE)) / (norm_k * r);
     wave_lds_fence();
+    PAIR_LAP(4)
     return ok;
 }
 
