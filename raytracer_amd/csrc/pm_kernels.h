@@ -336,15 +336,16 @@ __global__ __launch_bounds__(256) void k_shadow(SceneView gs, FrameParams fp, SP
 __device__ inline uint32_t sp_f2ord(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ inline float sp_ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
 // slot of the i-th shade point that is sorted: the bounced pixels' points first, then the listed points of spread-out tiles
-__device__ inline uint32_t sp_sorted_slot(const Counters *ctr, const uint32_t *loose, uint32_t i) {
-    return i < ctr->n_bounced ? ctr->n_sp0 + i : loose[i - ctr->n_bounced];
+// (clamped to the queue: after an overflow -- the frame is rendered again -- a listed slot may lie beyond it or not have been written)
+__device__ inline uint32_t sp_sorted_slot(const Counters *ctr, const uint32_t *loose, uint32_t i, uint32_t cap) {
+    return min(i < ctr->n_bounced ? ctr->n_sp0 + i : loose[i - ctr->n_bounced], cap - 1u);
 }
 __global__ __launch_bounds__(256) void k_sp_bounds(SPQueue q, const Counters *ctr, const uint32_t *loose, uint32_t *bounds) {
     __shared__ uint32_t part[4][6];
     const uint32_t n = ctr->n_sorted;
     uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0, 0, 0};
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t slot = sp_sorted_slot(ctr, loose, i);
+        const uint32_t slot = sp_sorted_slot(ctr, loose, i, q.cap);
         for (int a = 0; a < 3; a++) {
             uint32_t v = sp_f2ord((float)q.geo[a * (size_t)q.cap + slot]);
             mn[a] = min(mn[a], v); mx[a] = max(mx[a], v);
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256) void k_sp_morton(SPQueue q, const Counters *ct
     const uint32_t n = ctr->n_sorted;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t slot = sp_sorted_slot(ctr, loose, i);
+    const uint32_t slot = sp_sorted_slot(ctr, loose, i, q.cap);
     float ext = 0.f;
     for (int a = 0; a < 3; a++) ext = fmaxf(ext, sp_ord2f(bounds[3 + a]) - sp_ord2f(bounds[a]));
     uint32_t qv[3];

@@ -127,6 +127,28 @@ def test_a_frame_that_overflows_its_queue_is_reported(gpu_ctx, monkeypatch):
     g.destroy(); c.destroy()
 
 
+def test_an_overflowing_frame_with_spread_out_tiles(monkeypatch):
+    """The same on the 10 000 sphere scene with the deep tiles listed for the spatial sort (PM_LOOSE_TILES): a queue that is
+    too small must not send the kernels behind it out of bounds through that list."""
+    import raytracer_amd as ra
+    monkeypatch.setenv("PM_LOOSE_TILES", "2")
+    ctx = ra.Context(0)
+    try:
+        ctx.upload_scene(ra.many_spheres_scene())
+        g = ctx.create_map(0, 4096, 1); c = ctx.create_map(1, 4096, 1)
+        rp = ctx.params(320, 200, 1)
+        good, _ = ctx.render(g, c, rp)
+        monkeypatch.setenv("PM_SP_CAP_LIMIT", "1500")
+        with pytest.raises(ra.PMError, match="shade point queue overflowed"):
+            ctx.render(g, c, rp)
+        monkeypatch.delenv("PM_SP_CAP_LIMIT")
+        again, _ = ctx.render(g, c, rp)
+        assert np.array_equal(good, again)
+        g.destroy(); c.destroy()
+    finally:
+        ctx.close()
+
+
 def test_a_failed_map_fails_every_frame_that_uses_it(gpu_ctx):
     """One good map and one assembled from shards that hold too few photons: pm_render reports the bad map on every call
     (not only the first), nothing is left running behind the error, and the good map still renders afterwards."""
