@@ -90,7 +90,8 @@ struct pm_ctx {
     bool loose_auto = true;           // ... decided from the frame before: on when many tile groups were handed over as too spread out
     bool loose_on = false;            //     (many small objects), off again when few tiles are that deep; PM_LOOSE_TILES set: always as told
     bool emit_stream = true;          // sphere grid: emission as a stream of attempts per wave (PM_EMIT_STREAM=0: one attempt per lane, for A/B runs)
-    int emit_blocks = 512;            // blocks of k_emit_stream per launch: two maps side by side fill 256 CUs x 4 blocks (PM_EMIT_BLOCKS)
+    int emit_blocks = 384;            // blocks of k_emit_stream per launch: two maps side by side take three quarters of 256 CUs x 4 blocks and leave
+                                      // room for the frame's first passes (PM_EMIT_BLOCKS; 320 ... 448: 7.84 ms per step on 10 000 spheres, 512 / 640: 7.95)
     bool shadow_queue = true;         // sphere grid: the rays of a wave share a queue of tests (PM_SHADOW_QUEUE=0: every ray tests on its own, for A/B runs)
     bool shadow_per_ray = true;       // one lane per shadow ray rather than per shade point (PM_SHADOW_PER_RAY=0: the latter, for A/B runs)
     int scene_mode = SCENE_LDS;   // SCENE_LDS: staged per block; SCENE_GLOBAL: read in place; SCENE_GRID: in place, through the sphere grid
