@@ -10,6 +10,10 @@
 //   --out FILE    image file (default raytraced.png, the reference's name)
 //   --scene WHAT  a scene other than the reference's Cornell box: a scene file (raytrace::loadScene: `*.bin` = pm_prim
 //                 records, else text), `caustics` (BASELINE config 4), `spheres:N[:SEED]` (config 5: the walls + N spheres)
+//   --rank R --world N --id-file PATH
+//                 one process per GPU (raytrace_dist.h): this process is rank R of N, each started with its own GPU visible
+//                 (HIP_VISIBLE_DEVICES); rank 0 writes RCCL's unique id to PATH, the others wait for it; rank 0 writes the
+//                 image.  Also RANK / WORLD_SIZE from the environment when --id-file is given.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -17,6 +21,7 @@
 #include <vector>
 
 #include "raytrace_api.h"
+#include "raytrace_dist.h"
 
 namespace {
 
@@ -27,6 +32,8 @@ struct Options {
     long long seed = 0;
     std::string out = "raytraced.png";
     std::string scene;
+    int rank = 0, world = 0;          // world > 0: one process per GPU
+    std::string id_file;
 };
 
 // One line per way the reference turns a command line down, in the order it checks them.
@@ -43,15 +50,23 @@ bool parse(int argc, char *argv[], Options &o, std::vector<const char *> &positi
     if (const char *e = std::getenv("RAYTRACER_PHOTONS")) o.photons = std::atoll(e);
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
-        const bool wants_value = a == "--photons" || a == "--seed" || a == "--out" || a == "--scene";
+        const bool wants_value = a == "--photons" || a == "--seed" || a == "--out" || a == "--scene" || a == "--rank" || a == "--world" || a == "--id-file";
         if (!wants_value) { positional.push_back(argv[i]); continue; }
         if (i + 1 >= argc) return false;
         const char *v = argv[++i];
         if (a == "--photons") o.photons = std::atoll(v);
         else if (a == "--seed") { o.have_seed = true; o.seed = std::atoll(v); }
         else if (a == "--scene") o.scene = v;
+        else if (a == "--rank") o.rank = std::atoi(v);
+        else if (a == "--world") o.world = std::atoi(v);
+        else if (a == "--id-file") o.id_file = v;
         else o.out = v;
     }
+    if (!o.id_file.empty() && o.world == 0) {
+        if (const char *e = std::getenv("WORLD_SIZE")) o.world = std::atoi(e);
+        if (const char *e = std::getenv("RANK")) o.rank = std::atoi(e);
+    }
+    if (o.world > 0 && (o.id_file.empty() || o.rank < 0 || o.rank >= o.world)) return false;
     return true;
 }
 
@@ -82,6 +97,10 @@ int main(int argc, char *argv[]) {
             scene = raytrace::manySpheresScene((int32)n, seed);
         } else if (!(scene = raytrace::loadScene(o.scene.c_str()))) return 1;
     }
-    raytrace::render(o.out.c_str(), o.width, o.height, o.samples, scene);
+    if (o.world > 0) {
+        raytrace::RankGroup *group = raytrace::joinRanks(o.rank, o.world, o.id_file.c_str());
+        raytrace::renderRanks(group, o.out.c_str(), o.width, o.height, o.samples, scene);
+        raytrace::leaveRanks(group);
+    } else raytrace::render(o.out.c_str(), o.width, o.height, o.samples, scene);
     return 0;
 }

@@ -2,6 +2,7 @@
 // No ray is traced and no photon is stored on the CPU here: every function forwards to
 // libraytracer_amd.so and aborts with a message if the GPU backend reports an error.
 #include "raytrace_api.h"
+#include "raytrace_backend.h"
 
 #include <chrono>
 #include <cmath>
@@ -55,6 +56,16 @@ uint64_t seed() {
     return g_seed;
 }
 }  // namespace
+
+// what raytrace_dist.cpp (the one-process-per-GPU frame) needs of this file's state
+namespace raytrace { namespace backend {
+pm_ctx *context() { return ctx(); }
+void uploadScene(Scene *scene) { upload(scene); }
+unsigned long long frameSeed() { return seed(); }
+void photonCounts(int32 *global_photons, int32 *caustic_photons) { *global_photons = g_global_photons; *caustic_photons = g_caustic_photons; }
+void checked(int rc, const char *what) { check(rc, what); }
+bool writeImage(const char *file, int width, int height, const uint32 *words);
+} }
 
 namespace raytrace {
 
@@ -428,6 +439,10 @@ void render(const char *image_file, int32 width, int32 height, int32 sample_rati
     // so red and blue are swapped in its files; same bytes here
     if (!write_png(image_file, width, height, reinterpret_cast<const unsigned char *>(sample.data())))
         std::fprintf(stderr, "raytracer_amd: cannot write %s\n", image_file);
+}
+
+namespace backend {
+bool writeImage(const char *file, int width, int height, const uint32 *words) { return write_png(file, width, height, reinterpret_cast<const unsigned char *>(words)); }
 }
 
 }  // namespace raytrace

@@ -181,3 +181,36 @@ def test_cli_renders_a_scene_file(tmp_path, orc, scene, samples):
     red, green, blue = [x[::-1] for x in ch]
     assert np.array_equal(img[..., 0], blue) and np.array_equal(img[..., 1], green) and np.array_equal(img[..., 2], red)
     g.close(); c.close()
+
+
+def _run_ranks(tmp_path, world, args, env, out_name):
+    """One raytracer process per rank, all started at once (one process per GPU: rank r sees GPU r as device 0)."""
+    id_file = tmp_path / f"rccl_id_{out_name}"
+    procs = []
+    for r in range(world):
+        e = dict(env, HIP_VISIBLE_DEVICES=str(r)) if world > 1 else dict(env)
+        procs.append(subprocess.Popen([EXE, "--rank", str(r), "--world", str(world), "--id-file", str(id_file), "--out", out_name] + args,
+                                      cwd=tmp_path, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se
+    return outs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2])
+def test_cli_one_process_per_gpu_over_rccl(tmp_path, world):
+    """The C++ multi-GPU frame (raytrace_dist.h: attempt ranges per rank, one RCCL all-gather of the photon shards per map,
+    interleaved row blocks sent to rank 0): the PNG of N ranks equals the PNG of the single-GPU path byte for byte.
+    One rank exercises RCCL and the shard path on any box; two need two GPUs."""
+    import torch
+    if world > torch.cuda.device_count():
+        pytest.skip(f"{world} GPUs needed, {torch.cuda.device_count()} visible")
+    w, h, s, n, seed = 320, 180, 2, 20000, 31
+    e = dict(os.environ, RAYTRACER_SEED=str(seed), RAYTRACER_PHOTONS=str(n))
+    args = ["--scene", "caustics", "8", str(w), str(h), str(s)]
+    r = subprocess.run([EXE, "--out", "single.png"] + args, cwd=tmp_path, env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    outs = _run_ranks(tmp_path, world, args, e, "ranks.png")
+    assert "photon maps" in outs[0][0] and f"on {world} ranks" in outs[0][0]
+    assert (tmp_path / "ranks.png").read_bytes() == (tmp_path / "single.png").read_bytes()
