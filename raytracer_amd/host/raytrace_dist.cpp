@@ -50,12 +50,13 @@ struct RankGroup {
     DeviceBuffer mine[2], every[2], pane, probe;
     double yield[2] = {0, 0};        // stored photons per attempt of the uploaded scene, probed once per scene
     std::vector<unsigned char> probed_for;
+    std::string id_file;
 };
 
 RankGroup *joinRanks(int32 rank, int32 world, const char *id_file) {
     if (world < 1 || rank < 0 || rank >= world || world > 64 || !id_file) { std::fprintf(stderr, "raytracer_amd: joinRanks needs 0 <= rank < world <= 64 and an id file\n"); std::abort(); }
     RankGroup *g = new RankGroup();
-    g->rank = rank; g->world = world;
+    g->rank = rank; g->world = world; g->id_file = id_file;
     pm_ctx *ctx = backend::context();            // before RCCL: the library's streams get hardware queues of their own
     hip_ok(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking), "hipStreamCreate");
     backend::checked(pm_ctx_set_stream(ctx, g->stream), "pm_ctx_set_stream");
@@ -84,6 +85,7 @@ void leaveRanks(RankGroup *g) {
     backend::checked(pm_ctx_synchronize(backend::context()), "pm_ctx_synchronize");
     backend::checked(pm_ctx_set_stream(backend::context(), nullptr), "pm_ctx_set_stream");
     if (g->comm) (void)ncclCommDestroy(g->comm);
+    if (g->rank == 0) (void)std::remove(g->id_file.c_str());      // every rank has long read it: the next group starts from a fresh file
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
 }

@@ -8,7 +8,8 @@
 //
 //   rank 0..world-1, one process each, each with its own GPU visible as device 0 (HIP_VISIBLE_DEVICES) or
 //   scheduler::startWorkers called after hipSetDevice; id_file: a path all ranks can read -- rank 0 writes RCCL's
-//   unique id there, the others wait for it.
+//   unique id there, the others wait for it.  The file must not exist when the ranks start (a stale one would be read as
+//   the id); rank 0 removes it in leaveRanks.
 #pragma once
 #include "raytrace_api.h"
 
