@@ -149,6 +149,7 @@ def main():
     ap.add_argument("--cpu-row-stride", type=int, default=1)
     ap.add_argument("--cpu-cores", type=int, default=0, help="threads of the CPU baseline (default: the cores this process may run on)")
     ap.add_argument("--check", action="store_true", help="compare the CPU sample rows with the GPU pane")
+    ap.add_argument("--check-hash", action="store_true", help="add the SHA-1 of the last timed step's pane to the line (A/B runs: same bits?)")
     ap.add_argument("--dump-pane", default="", help="rank 0 writes the final pane (uint32 raw) to this file")
     args = ap.parse_args()
 
@@ -356,6 +357,9 @@ def main():
                 rows = slice(args.cpu_row_stride // 2, args.height, args.cpu_row_stride)
                 cb["sample_rows_bit_identical_to_gpu"] = bool(np.array_equal(gp[rows], cpane[rows]))
             out["cpu_baseline"] = cb
+        if args.check_hash and last_pane is not None:
+            import hashlib
+            out["pane_sha1"] = hashlib.sha1(last_pane.cpu().numpy().tobytes()).hexdigest()
         if args.dump_pane and last_pane is not None:
             last_pane.cpu().numpy().tofile(args.dump_pane)      # the pane the last timed step gathered on rank 0
         sys.stdout.flush()

@@ -30,6 +30,9 @@ namespace pm {
 #define PM_TILE_EST_MAX 1600   // expected size of the shared set beyond which a group is left to the per-query kernel: one wave
                               // would sit on it for many times the average while independent queries spread over the device
 #endif
+#ifndef PM_TILE_FENCE
+#define PM_TILE_FENCE 1
+#endif
 #ifndef PM_TS_CAP
 #define PM_TS_CAP 2048
 #endif
@@ -170,8 +173,15 @@ __device__ inline int tile_collect(TileBuf *tb, const Strip &S, const MapView &m
     // far-away sentinels behind the last candidate: the passes work in whole batches and need no index test
 #pragma unroll
     for (int u = 0; u < TS_CHUNK / 64; u++) S.x[ns + u * 64 + lane] = 3.0e18f;
-    // the strip is read back through the vector caches by this same wave: writes done, stale lines of the previous group dropped
+    // The strip is read back through the vector caches by this same wave: its writes must have reached the L2 (the wave
+    // waits for them) and the lines of the previous group's strip must be gone from the CU's vector cache (buffer_inv).
+    // An agent-scope fence does both -- and, on gfx950, a write-back of the XCD's whole L2 before it (buffer_wbl2), once
+    // per group: 2.72 -> 2.55 ms per step without that (PM_TILE_FENCE=0 brings the fence back for A/B runs; same panes).
+#if PM_TILE_FENCE == 0
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+#else
+    asm volatile("s_waitcnt vmcnt(0)\n\tbuffer_inv sc1" ::: "memory");
+#endif
     wave_lds_fence();
     return ns;
 }
