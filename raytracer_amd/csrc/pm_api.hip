@@ -459,6 +459,15 @@ extern "C" int pm_pair_ticks(unsigned long long *out8, int reset) {
     return 0;
 }
 #endif
+#ifdef PM_WAVE_TIMES
+extern "C" int pm_tile_waves(uint32_t *out, int reset) {     // 2 x 8192 x 4 words per wave, then 2 x 16384 x 2 words per group
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_waves), sizeof(uint32_t) * 2 * 8192 * 4) != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out + 2 * 8192 * 4, HIP_SYMBOL(g_tile_groups), sizeof(uint32_t) * 2 * 16384 * 2) != hipSuccess) return -1;
+    if (reset) { static std::vector<uint32_t> z(2 * 8192 * 4, 0u); if (hipMemcpyToSymbol(HIP_SYMBOL(g_tile_waves), z.data(), z.size() * 4) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 #ifdef PM_TRACE_STATS
 extern "C" int pm_trace_stats(unsigned long long *out16, int reset) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
@@ -1025,6 +1034,7 @@ static int gather_blocks(pm_ctx *ctx) {
     ctx->tile_blocks = std::max(8, std::max(1, per_cu_t) * cus / 8 * 8);
     ctx->query_blocks = std::max(8, std::max(1, per_cu_q) * cus / 8 * 8);
     ctx->pair_blocks = std::max(8, std::max(1, per_cu_p) * cus / 8 * 8);
+    if (const char *v = getenv("PM_TILE_BLOCKS")) { int x = atoi(v); if (x >= 8 && x <= ctx->tile_blocks) ctx->tile_blocks = x / 8 * 8; }   // experiments: fewer resident groups
     if (const char *v = getenv("PM_PAIR")) ctx->use_pairs = v[0] != '0';
     const char *e = getenv("PM_GATHER_TILE");
     ctx->use_tiles = !(e && e[0] == '0');

@@ -581,7 +581,10 @@ __global__ __launch_bounds__(256) void k_gather(MapView m_in, SPQueue q, const u
 // query cannot answer (far from the photons, a dense cluster next door) is then taken by the whole wave with the octree walk,
 // right here.  The kernel the frame uses (PM_PAIR=0: k_gather, for A/B runs).
 template <int KIND>
-__global__ __launch_bounds__(256) void k_gather_pair(MapView m_in, SPQueue q, const uint32_t *left, const uint32_t *n_left, const Counters *ctr, int sec_mode,
+#ifndef PM_PAIR_WAVES
+#define PM_PAIR_WAVES 3
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM_PAIR_WAVES, PM_PAIR_WAVES))) void k_gather_pair(MapView m_in, SPQueue q, const uint32_t *left, const uint32_t *n_left, const Counters *ctr, int sec_mode,
                                                      uint32_t *sched) {
     MapView m = m_in;
     load_grid(m);
@@ -635,10 +638,18 @@ __global__ __launch_bounds__(256) void k_gather_pair(MapView m_in, SPQueue q, co
     }
 }
 
+#ifdef PM_WAVE_TIMES
+// diagnostics (builds with -DPM_WAVE_TIMES only): per wave of the latest k_gather_tile launch of each map {first tick, last tick, groups, XCD}
+static __device__ uint32_t g_tile_waves[2][8192][4];
+static __device__ uint32_t g_tile_groups[2][16384][2];     // per group {start, end} on the device-wide clock
+#endif
+#ifndef PM_TILE_WAVES
+#define PM_TILE_WAVES 4
+#endif
 // One wave per GROUP of shade points (pm_tile.h): the shade points of one 8x8 pixel tile, one per lane.  A group that
 // cannot be gathered as a group appends its slots to `left` for k_gather.
 template <int KIND>
-__global__ __launch_bounds__(64) void k_gather_tile(MapView m_in, SPQueue q, const uint2 *groups, const Counters *ctr, uint32_t *left, uint32_t *n_left,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PM_TILE_WAVES, PM_TILE_WAVES))) void k_gather_tile(MapView m_in, SPQueue q, const uint2 *groups, const Counters *ctr, uint32_t *left, uint32_t *n_left,
                                                     uint32_t *sched, float4 *strips, int dbg, const uint32_t *sorted, const uint2 *sgroups, uint32_t part, uint32_t nparts) {
     MapView m = m_in;
     load_grid(m);
@@ -653,8 +664,18 @@ __global__ __launch_bounds__(64) void k_gather_tile(MapView m_in, SPQueue q, con
     const uint32_t g_lo = (uint32_t)((unsigned long long)n_groups * part / nparts), g_hi = (uint32_t)((unsigned long long)n_groups * (part + 1u) / nparts);
     WorkDraw wd;
     uint32_t i0, i1;
+#ifdef PM_WAVE_TIMES
+    const unsigned long long wt0 = __builtin_amdgcn_s_memrealtime();      // (the device-wide 100 MHz clock: s_memtime counts per XCD)
+    uint32_t wgroups = 0;
+    if (lane == 0 && blockIdx.x < 8192) { uint32_t *o = g_tile_waves[KIND][blockIdx.x]; o[0] = (uint32_t)wt0; o[1] = (uint32_t)wt0; o[2] = 0; o[3] = wd.xcd | ((uint32_t)__builtin_amdgcn_s_getreg(20 | (3 << 11)) << 8); }   // (hardware register 20: XCC_ID, 4 bits)
+#endif
     while (wd.next(sched, g_hi - g_lo, 1u, i0, i1)) {
         i0 += g_lo;
+#ifdef PM_WAVE_TIMES
+        const uint32_t gt0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        wgroups++;
+        if (lane == 0 && blockIdx.x < 8192) { uint32_t *o = g_tile_waves[KIND][blockIdx.x]; o[2] = wgroups; }
+#endif
 #ifdef PM_TILE_STAMPS
         const unsigned long long tg0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -693,6 +714,10 @@ __global__ __launch_bounds__(64) void k_gather_tile(MapView m_in, SPQueue q, con
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
             if (dead) left[base + (uint32_t)lane_rank(lm)] = s;
         }
+#ifdef PM_WAVE_TIMES
+        if (lane == 0 && blockIdx.x < 8192) g_tile_waves[KIND][blockIdx.x][1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        if (lane == 0 && i0 < 16384) { g_tile_groups[KIND][i0][0] = gt0; g_tile_groups[KIND][i0][1] = (uint32_t)__builtin_amdgcn_s_memrealtime(); }
+#endif
     }
 }
 

@@ -43,14 +43,17 @@ constexpr int TS_BINL = 8;         // photons of the crossing bin a lane can ran
 #define PM_TS_BATCH 8
 #endif
 constexpr int TS_BATCH = PM_TS_BATCH;   // candidates fetched ahead in the selection passes
-constexpr int TS_MROW = 66;        // member list row stride in 16-bit entries: 33 words, conflict-free by row and by column
+constexpr int TS_MROW = 68;        // member list row stride in BYTES: 17 words, conflict-free by row and by column
+constexpr int TS_PAGE = 256;       // a member is stored as its candidate index modulo TS_PAGE (one byte); the lane remembers where its pages begin
+static_assert(TS_CAP <= 8 * TS_PAGE, "eight pages of candidates: their first members fit two registers, a byte each");
 
 // per-wave LDS of the selection; the shared set S itself lives in a per-wave strip of device memory (it is read
-// front to back by all lanes at once, so every read is one broadcast cache line)
+// front to back by all lanes at once, so every read is one broadcast cache line).
+// 9.25 KB: sixteen waves per compute unit (the member lists were 16-bit entries once, 13.25 KB and eleven waves).
 struct TileSel {
     uint32_t hist[(TS_BINS / 4) * 64];             // [word][lane]
-    uint16_t member[64 * TS_MROW];                 // [lane][k]
-    uint16_t binl[TS_BINL * 64];                   // [k][lane]
+    uint8_t member[64 * TS_MROW];                  // [lane][k]: candidate index & 255 of the lane's k-th member for sure, in ascending order
+    uint16_t binl[TS_BINL * 64];                   // [k][lane]: the uncertain band; after the ranking, those of it that are members
 };
 struct alignas(16) TileBuf {
     union { KnnBuf knn; TileSel sel; };    // the centre query and the range walk are over before the selection starts
@@ -197,8 +200,8 @@ __device__ inline double tile_d2(const float4 &s, const V3 &p) {   // src/Photon
 // and read from there by all lanes at once (broadcast reads), TS_BATCH candidates per step.
 // stage: 2 * 3 * TS_CHUNK floats of LDS not otherwise in use during the pass.
 typedef float f2 __attribute__((ext_vector_type(2)));
-template <class F>
-__device__ inline void tile_pass(float *stage, const Strip &S, int ns, float pxf, float pyf, float pzf, F fn) {
+template <class F, class C>
+__device__ inline void tile_pass(float *stage, const Strip &S, int ns, float pxf, float pyf, float pzf, F fn, C chunk_fn) {
     static_assert(TS_CHUNK == 128 && TS_BATCH == 8, "two candidates per lane and chunk; batches of eight");
     const int lane = threadIdx.x & 63;
     const f2 px2 = {pxf, pxf}, py2 = {pyf, pyf}, pz2 = {pzf, pzf};
@@ -215,6 +218,7 @@ __device__ inline void tile_pass(float *stage, const Strip &S, int ns, float pxf
             rx = *reinterpret_cast<const f2 *>(S.x + o); ry = *reinterpret_cast<const f2 *>(S.y + o); rz = *reinterpret_cast<const f2 *>(S.z + o);
         }
         const int jn = min(ns - c * TS_CHUNK, TS_CHUNK);
+        chunk_fn(c);
         for (int j0 = 0; j0 < jn; j0 += TS_BATCH) {
             const float4 xa = *reinterpret_cast<const float4 *>(b + j0), xb = *reinterpret_cast<const float4 *>(b + j0 + 4);
             const float4 ya = *reinterpret_cast<const float4 *>(b + TS_CHUNK + j0), yb = *reinterpret_cast<const float4 *>(b + TS_CHUNK + j0 + 4);
@@ -312,7 +316,7 @@ __device__ inline bool tile_gather(TileBuf *tb, const Strip &S, const MapView &m
             atomicAdd(&sel.hist[(bin >> 2) * 64 + lane], 1u << (8 * (bin & 3)));
             n_in++;
         }
-    });
+    }, [](int) {});
     wave_lds_fence();
     int bstar = -1;
     uint32_t cum = 0;
@@ -337,15 +341,25 @@ __device__ inline bool tile_gather(TileBuf *tb, const Strip &S, const MapView &m
     bool ok = active && bstar >= 0 && cum == n_in && hi_e + 2.0 * g < (double)Lf;
     if (__ballot(ok) == 0ULL) { why = 5; return false; }
     const float lo_t = ok ? __double2float_rd(lo_e - 2.0 * g) : -1.0f, hi_t = ok ? __double2float_ru(hi_e + 2.0 * g) : -1.0f;
-    // pass 2: members for sure, list of the uncertain band
+    // pass 2: members for sure, list of the uncertain band.  A member is stored as one byte, its index in S modulo TS_PAGE;
+    // candidates come in ascending order, so all it takes to get the index back is the number of members the lane had when
+    // each page of S began (pg_lo / pg_hi: a byte per page, 255 = the page was never reached; at most 62 members are sure).
     int mc = 0, bc = 0;
+    uint32_t pg_lo = 0xFFFFFFFFu, pg_hi = 0xFFFFFFFFu;
     tile_pass(reinterpret_cast<float *>(sel.hist), S, ns, pxf, pyf, pzf, [&](int j, float d2f) {   // (the histogram is done)
         // (the two counters are advanced outside the branches: merged into one conditional store they end up in memory)
         const bool sure = d2f < lo_t, band = !sure && d2f <= hi_t;
-        if (sure) sel.member[lane * TS_MROW + mc] = (uint16_t)j;
+        if (sure) sel.member[lane * TS_MROW + mc] = (uint8_t)j;
         if (band && bc < TS_BINL) sel.binl[bc * 64 + lane] = (uint16_t)j;
         mc += sure ? 1 : 0;
         bc += band ? 1 : 0;
+    }, [&](int c) {
+        constexpr int per_page = TS_PAGE / TS_CHUNK;
+        if (c % per_page == 0) {
+            const int pgn = c / per_page, sh = 8 * (pgn & 3);
+            if (pgn < 4) pg_lo = (pg_lo & ~(0xFFu << sh)) | ((uint32_t)mc << sh);
+            else pg_hi = (pg_hi & ~(0xFFu << sh)) | ((uint32_t)mc << sh);
+        }
     });
     TS_LAP(3)
     // exact d2 of the uncertain band (positions from the map itself), then the exact rank: r = the entry with fewer than
@@ -369,9 +383,14 @@ __device__ inline bool tile_gather(TileBuf *tb, const Strip &S, const MapView &m
         for (int b = 0; b < TS_BINL; b++) { less += bd[b] < bd[a]; leq += bd[b] <= bd[a]; }
         if (a < bc && less < need && need <= leq) r = bd[a];
     }
+    // those of the band that are members follow the sure ones, listed by their full index (the band's own list is reused:
+    // entry bm is never beyond the entry it came from)
+    int bm = 0;
 #pragma unroll
     for (int a = 0; a < TS_BINL; a++)
-        if (a < bc && bd[a] < r) { sel.member[lane * TS_MROW + mc] = bj[a]; mc++; }   // d2 == r has weight 0
+        if (a < bc && bd[a] < r) { sel.binl[bm * 64 + lane] = bj[a]; bm++; }   // d2 == r has weight 0
+    const int mc_sure = mc;
+    mc += bm;
     wave_lds_fence();
     TS_LAP(4)
     // 4. radiance: every lane sums its own members (canonical sum: 64-bit fixed point, 2^-56 resolution)
@@ -381,7 +400,16 @@ __device__ inline bool tile_gather(TileBuf *tb, const Strip &S, const MapView &m
     long long aR = 0, aG = 0, aB = 0;
     const RDiv rd = rdiv_make(r);
     // three stages in flight: photon index of members k+4, k+5; the two records of members k+2, k+3; the terms of k, k+1
-    auto index_of = [&](int k) -> uint32_t { return k < mc ? S.idx[sel.member[lane * TS_MROW + k]] : 0u; };
+    // (index_of is called for k = 0, 1, 2, ... in turn: the page of the k-th sure member is found by walking on)
+    int page = 0;
+    const unsigned long long pages = ((unsigned long long)pg_hi << 32) | pg_lo;
+    int page_end = (int)((pages >> 8) & 255u);            // members the lane had when the next page began
+    auto index_of = [&](int k) -> uint32_t {
+        if (k >= mc) return 0u;
+        if (k >= mc_sure) return S.idx[sel.binl[(k - mc_sure) * 64 + lane]];
+        while (k >= page_end) { page++; page_end = page < 7 ? (int)((pages >> (8 * (page + 1))) & 255u) : 255; }
+        return S.idx[page * TS_PAGE + (int)sel.member[lane * TS_MROW + k]];
+    };
     auto term = [&](int k, const float4 &s, const uint4 &rr) {
         if (k < mc) {
             long long fr, fg, fb;
