@@ -33,12 +33,15 @@ WORKLOAD = {"default": "default Cornell scene", "spheres10k": "five walls + 10,0
             "caustics": "five walls + five glass spheres (BASELINE config 4 scene),"}
 
 
-# One SIMD issues an FP64 wave-instruction every ~2.2 ns when all of them are busy (tools/microbench/valu_rates.hip, profiles/r01/valu_rates.txt): 1024 SIMDs.
+# One SIMD issues an FP64 wave-instruction every ~2.2 ns when all of them are busy (tools/microbench/valu_rates.hip, re-run in round 3:
+# profiles/r03/valu_rates.txt): 1024 SIMDs.  The spec-derived figure beside it: 78.6 TFLOP/s FP64 vector / 2 (an FMA counts twice) / 64 lanes.
 VALU_PEAK_GINSTR_S = 1024 / 2.2
+VALU_SPEC_GINSTR_S = 78.6e12 / 2 / 64 / 1e9
+N_SIMDS = 1024
 # FP64 vector peak 78.6 TFLOP/s counts an FMA as two; contraction is off here (bit-exactness), so 39.3 T non-fused flop/s
 FP64_PEAK_TFLOPS = 39.3
 FLOP_PER_SPHERE_TEST, FLOP_PER_PLANE_TEST = 22, 6
-PMC_PASSES = (("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES"), ("FETCH_SIZE",), ("WRITE_SIZE",))   # FETCH_SIZE and WRITE_SIZE do not fit one pass
+PMC_PASSES = (("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"), ("FETCH_SIZE",), ("WRITE_SIZE",))   # FETCH_SIZE and WRITE_SIZE do not fit one pass
 
 
 def under_profiler():
@@ -60,7 +63,7 @@ def live_pmc(args):
         return {}, "rocprofv3 not found"
     if under_profiler():
         return {}, "already running under a profiler"
-    child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pmc", "--scene", args.scene,
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pmc", "--pmc-child", "--scene", args.scene,
              "--width", str(args.width), "--height", str(args.height), "--photons", str(args.photons), "--seed", str(args.seed)]
     acc = {}
     env = dict(os.environ, TMPDIR="/tmp")
@@ -146,6 +149,7 @@ def main():
                     help="default = BASELINE config 2 (the bench line); spheres10k / caustics = the synthetic scenes of configs 5 / 4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (roofline.traffic and the instruction counts are then null)")
+    ap.add_argument("--pmc-child", action="store_true", help="(internal) a child run under rocprofv3: the timed steps only, no counting frame, no host-pane loop")
     ap.add_argument("--cpu-row-stride", type=int, default=1)
     ap.add_argument("--cpu-cores", type=int, default=0, help="threads of the CPU baseline (default: the cores this process may run on)")
     ap.add_argument("--check", action="store_true", help="compare the CPU sample rows with the GPU pane")
@@ -253,7 +257,7 @@ def main():
     # after the timed region, one more frame that counts the primitive tests of the primary and the shadow pass (same pane,
     # counting kernels: the intersection roofline needs tests, not rays, once a scene is walked through the sphere grid)
     tests = None
-    if not use_dist:
+    if not use_dist and not args.pmc_child:
         frame.flags |= ra.PM_FLAG_COUNT_TESTS
         stc = frame.render()
         frame.flags &= ~ra.PM_FLAG_COUNT_TESTS
@@ -264,60 +268,98 @@ def main():
         step_s = dt / args.steps
         ph = {k: v / args.steps for k, v in phase.items()}
         pmc, pmc_note = ({}, "skipped (--no-pmc)") if args.no_pmc or use_dist else live_pmc(args)
-        # The dominant kernel of this workload, by device time per step (HIP events on the stream each runs on): the group
-        # gather of either map (one launch per map and step, side by side on two streams), the shadow pass or the primary pass.
-        cand = {"k_gather_tile<0>": ph["ms_group_global"], "k_gather_tile<1>": ph["ms_group_caustic"], "k_shadow_rays": ph["ms_shadow"], "k_primary": ph["ms_primary"]}
-        dom = max(cand, key=cand.get)
-        dom_ms = cand[dom]
-        c = kernel_counters(pmc, dom)
-        valu = c.get("SQ_INSTS_VALU")
-        issue = {"achieved": valu / (dom_ms * 1e-3) / 1e9, "peak": VALU_PEAK_GINSTR_S, "unit": "G wave-instr/s", "frac": valu / (dom_ms * 1e-3) / 1e9 / VALU_PEAK_GINSTR_S,
-                 "valu_instr_per_launch": valu, "salu_instr_per_launch": c.get("SQ_INSTS_SALU"),
-                 "note": "SQ_INSTS_VALU per launch (live PMC pass) / live launch time; peak = 1024 SIMDs x one FP64 wave-instruction per 2.2 ns "
-                         "(tools/microbench/valu_rates.hip); kernels of other streams share the device during that time"} if valu and dom_ms > 0 else None
-        if dom.startswith("k_gather_tile"):
-            k = 0 if dom.endswith("<0>") else 1
-            units = (st.grouped_global, st.grouped_caustic)[k]
-            hbm_ach = ALGO_BYTES_PER_GATHER * units / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-            roof = {"bound": "valu", "kernel": dom + (" (global map)", " (caustic map)")[k],
-                    "achieved": issue["achieved"] if issue else None, "peak": VALU_PEAK_GINSTR_S, "unit": "G wave-instr/s", "frac": issue["frac"] if issue else None,
-                    "traffic": hbm_traffic(c), "traffic_note": pmc_note,
-                    "hbm": {"achieved": hbm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_ach / HBM_PEAK_GBS,
-                            "note": f"SURVEY 8d's figure: algorithmic bytes = {ALGO_BYTES_PER_GATHER} B x {int(units)} gathers answered per launch / launch time; the maps "
-                                    "(64 MB + tables each) stay in L2 / Infinity Cache, so HBM is not what binds this kernel"},
-                    "valu_issue": issue,
-                    "note": f"avg launch {dom_ms:.3f} ms (HIP events on the stream the kernel is launched on; the other map's gather runs beside it on a second stream); "
-                            "the kernel is bound by vector instruction issue (FP64 arithmetic of the selection and of the radiance sum), which is the fraction reported"}
-        else:
-            which = "shadow" if dom == "k_shadow_rays" else "primary"
-            sph, pl = tests[which] if tests else (0, 0)
-            flop = sph * FLOP_PER_SPHERE_TEST + pl * FLOP_PER_PLANE_TEST
-            ach = flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-            roof = {"bound": "valu", "kernel": dom, "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
-                    "traffic": hbm_traffic(c), "traffic_note": pmc_note, "valu_issue": issue,
-                    "note": f"{sph} sphere tests x {FLOP_PER_SPHERE_TEST} + {pl} plane tests x {FLOP_PER_PLANE_TEST} flop (counted on the device by the counting variant of the pass, "
-                            f"same frame) / avg launch {dom_ms:.3f} ms; peak = FP64 vector without FMA contraction"}
-        # the intersection passes against the FP64 peak, whichever kernel dominates (north_star: VALU / occupancy for intersection)
-        inter = None
-        if tests:
-            inter = {}
-            for which, kern, ms in (("primary", "k_primary", ph["ms_primary"]), ("shadow", "k_shadow_rays", ph["ms_shadow"])):
-                sph, pl = tests[which]
+        # Every kernel class of the step with a device time of its own (HIP events on the stream it runs on), its roofline, and
+        # the dominant one: the class with the most device time per step.  The two maps' launches of one kernel template are
+        # one class (two launches per step): which of the two is the longer flips from run to run with how they overlap.
+        em_name = "k_emit_stream" if kernel_counters(pmc, "k_emit_stream") or args.scene == "spheres10k" else "k_emit"
+        pq_name = "k_gather" if (pmc and not kernel_counters(pmc, "k_gather_pair<0>")) else "k_gather_pair"
+        n_maps = 2
+        left = [st.left_global, st.left_caustic]
+        classes = {
+            "k_gather_tile": {"launches": n_maps, "ms": (ph["ms_group_global"] + ph["ms_group_caustic"]) / n_maps, "pmc": ("k_gather_tile<0>", "k_gather_tile<1>"),
+                              "gathers": (st.grouped_global + st.grouped_caustic) / n_maps,
+                              "what": "group gather (pm_tile.h), one launch per map, side by side on two streams"},
+            pq_name: {"launches": n_maps, "ms": max(0.0, (ph["ms_gather_global"] - ph["ms_group_global"]) + (ph["ms_gather_caustic"] - ph["ms_group_caustic"])) / n_maps,
+                      "pmc": (pq_name + "<0>", pq_name + "<1>"), "gathers": sum(left) / n_maps,
+                      "what": "per-query gather of what the group kernel left, behind it on its stream (the launch beside the group kernels, "
+                              f"{st.early_points} bounced pixels' shade points per map, has no events of its own; the counters average both launches)"},
+            "k_shadow_rays": {"launches": 1, "ms": ph["ms_shadow"], "pmc": ("k_shadow_rays",), "tests": tests["shadow"] if tests else None, "what": "shadow any-hit pass, one ray per lane"},
+            "k_primary": {"launches": 1, "ms": ph["ms_primary"], "pmc": ("k_primary",), "tests": tests["primary"] if tests else None, "what": "primary closest-hit pass"},
+            em_name: {"launches": n_maps, "ms": (map_ms[0][0] + map_ms[1][0]) / args.steps / n_maps, "pmc": (em_name,),
+                      "what": "photon emission of one map (events around k_emit + k_scan_blocks + k_emit_scatter: the first is nearly all of it)"},
+        }
+        clock_hz = torch.cuda.get_device_properties(local_rank).clock_rate * 1e3 if hasattr(torch.cuda.get_device_properties(local_rank), "clock_rate") else 2.4e9
+
+        def class_counters(names):
+            got = [kernel_counters(pmc, n) for n in names]
+            got = [g for g in got if g]
+            keys = set().union(*[g.keys() for g in got]) if got else set()
+            return {k: sum(g.get(k, 0.0) for g in got) / len(got) for k in keys}
+
+        def roofline_of(name, k):
+            c = class_counters(k["pmc"])
+            ms = k["ms"]
+            valu = c.get("SQ_INSTS_VALU")
+            issue = None
+            if valu and ms > 0:
+                ach = valu / (ms * 1e-3) / 1e9
+                issue = {"achieved": ach, "peak": VALU_PEAK_GINSTR_S, "unit": "G wave-instr/s", "frac": ach / VALU_PEAK_GINSTR_S,
+                         "frac_of_spec_fp64_rate": ach / VALU_SPEC_GINSTR_S, "spec_peak": VALU_SPEC_GINSTR_S,
+                         "valu_instr_per_launch": valu, "salu_instr_per_launch": c.get("SQ_INSTS_SALU")}
+            occ = None
+            if c.get("SQ_WAVE_CYCLES") and ms > 0:
+                # SQ_WAVE_CYCLES counts quad-cycles of resident waves (MI355X_MICROARCH.md): x 4 / (launch time x clock x SIMDs)
+                occ = {"waves_per_simd_achieved": 4.0 * c["SQ_WAVE_CYCLES"] / (ms * 1e-3 * clock_hz * N_SIMDS), "waves_per_launch": c.get("SQ_WAVES"),
+                       "sq_wave_cycles": c["SQ_WAVE_CYCLES"], "sq_busy_cycles": c.get("SQ_BUSY_CYCLES"), "clock_hz_assumed": clock_hz}
+            r = {"kernel": name, "launches_per_step": k["launches"], "ms_per_launch": ms, "ms_per_step": ms * k["launches"], "what": k["what"],
+                 "traffic": hbm_traffic(c), "valu_issue": issue, "occupancy": occ}
+            if "gathers" in k:
+                hbm_ach = ALGO_BYTES_PER_GATHER * k["gathers"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+                hbm = {"achieved": hbm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_ach / HBM_PEAK_GBS,
+                       "note": f"SURVEY 8d's figure: {ALGO_BYTES_PER_GATHER} B x {k['gathers']:.0f} gathers answered per launch / launch time; the maps (64 MB + tables "
+                               "each at 1M photons) stay in L2 / Infinity Cache, so HBM is not what binds this kernel"}
+                # the kernel is bound by its waves' instruction streams (FP64 selection and radiance arithmetic, memory latency): the issue
+                # fraction is the one reported; without counters (no rocprofv3, a failed pass) the HBM figure stands in, named as such
+                if issue:
+                    r.update({"bound": "valu", "achieved": issue["achieved"], "peak": VALU_PEAK_GINSTR_S, "unit": "G wave-instr/s", "frac": issue["frac"], "hbm": hbm})
+                else:
+                    r.update({"bound": "hbm", "achieved": hbm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_ach / HBM_PEAK_GBS, "hbm": hbm,
+                              "fallback": "no instruction counters in this run (" + pmc_note + "): SURVEY 8d's algorithmic HBM fraction instead of the issue fraction"})
+            elif k.get("tests") is not None or name in ("k_shadow_rays", "k_primary"):
+                sph, pl = k.get("tests") or (0, 0)
                 flop = sph * FLOP_PER_SPHERE_TEST + pl * FLOP_PER_PLANE_TEST
-                kc = kernel_counters(pmc, kern)
-                inter[kern] = {"ms": ms, "sphere_tests": sph, "plane_tests": pl, "tflops": flop / (ms * 1e-3) / 1e12 if ms > 0 else None,
-                               "frac_of_fp64_peak": flop / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if ms > 0 else None,
-                               "valu_instr_per_launch": kc.get("SQ_INSTS_VALU"), "waves_per_launch": kc.get("SQ_WAVES")}
+                ach = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+                r.update({"bound": "valu", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "sphere_tests": sph, "plane_tests": pl,
+                          "note": f"{sph} sphere tests x {FLOP_PER_SPHERE_TEST} + {pl} plane tests x {FLOP_PER_PLANE_TEST} flop (counted on the device by the counting variant "
+                                  "of the pass, same frame) / launch time; peak = FP64 vector without FMA contraction"})
+            else:
+                r.update({"bound": "valu", "achieved": issue["achieved"] if issue else None, "peak": VALU_PEAK_GINSTR_S, "unit": "G wave-instr/s",
+                          "frac": issue["frac"] if issue else None})
+            return r
+
+        roof_all = [roofline_of(n, k) for n, k in classes.items()]
+        roof = dict(max(roof_all, key=lambda r: r["ms_per_step"]))
+        roof["traffic_note"] = pmc_note
+        roof["note"] = (f"dominant kernel class of the step by device time ({roof['ms_per_step']:.3f} ms per step in {roof['launches_per_step']} launch(es), HIP events on the "
+                        "stream each launch runs on; kernels of other streams share the device during that time); valu peak = 1024 SIMDs x one FP64 "
+                        f"wave-instruction per 2.2 ns measured (profiles/r03/valu_rates.txt), spec-derived {VALU_SPEC_GINSTR_S:.0f} G/s beside it")
+        # the intersection passes against the FP64 peak, whichever kernel dominates (north_star: VALU / occupancy for intersection)
+        inter = {r["kernel"]: {"ms": r["ms_per_launch"], "sphere_tests": r.get("sphere_tests"), "plane_tests": r.get("plane_tests"), "tflops": r["achieved"],
+                               "frac_of_fp64_peak": r["frac"], "valu_issue_frac": r["valu_issue"]["frac"] if r["valu_issue"] else None,
+                               "valu_instr_per_launch": r["valu_issue"]["valu_instr_per_launch"] if r["valu_issue"] else None,
+                               "waves_per_simd_achieved": r["occupancy"]["waves_per_simd_achieved"] if r["occupancy"] else None,
+                               "waves_per_launch": r["occupancy"]["waves_per_launch"] if r["occupancy"] else None}
+                 for r in roof_all if r["kernel"] in ("k_primary", "k_shadow_rays")} if tests else None
         per_query = None
-        if pmc:
-            # the per-query kernel the frame used: two shade points per wave (k_gather_pair), or one (k_gather, PM_PAIR=0)
-            pq_name = "k_gather_pair" if kernel_counters(pmc, "k_gather_pair<0>") else "k_gather"
-            pq = [kernel_counters(pmc, pq_name + "<0>"), kernel_counters(pmc, pq_name + "<1>")]
-            if all("SQ_INSTS_VALU" in x for x in pq):
-                n_pq = [st.absorb_points - st.grouped_global, st.absorb_points - st.grouped_caustic]
-                tot = sum(2.0 * x["SQ_INSTS_VALU"] for x in pq)    # two launches per map and step: beside the group kernel, and behind it
-                per_query = {"gathers_per_step": int(sum(n_pq)), "valu_instr_per_gather": tot / max(1, sum(n_pq)),
-                             "kernel": pq_name + "<0/1>", "note": "SQ_INSTS_VALU per launch (live PMC pass) x 2 launches per map / shade points the group kernels did not answer"}
+        pqc = class_counters(classes[pq_name]["pmc"])
+        if pqc.get("SQ_INSTS_VALU"):
+            n_pq = [st.absorb_points - st.grouped_global, st.absorb_points - st.grouped_caustic]
+            # per map and step two launches of the kernel: beside the group kernel (the points never grouped) and behind it (what it left);
+            # the counters are the average over both launches of both maps, so x 4 is the step's total
+            tot = 4.0 * pqc["SQ_INSTS_VALU"]
+            per_query = {"gathers_per_step": int(sum(n_pq)), "valu_instr_per_gather": tot / max(1, sum(n_pq)), "kernel": pq_name + "<0/1>",
+                         "left_by_group_kernels": left, "never_grouped_per_map": st.early_points,
+                         "note": "SQ_INSTS_VALU averaged over the kernel's launches (live PMC pass) x 4 launches per step / shade points the group kernels did not answer"}
         config_tag = " (BASELINE config 2)" if (args.scene, args.width, args.height, args.photons) == ("default", 1440, 1440, 1000000) else ""
         out = {
             "metric": "Mrays/sec + photon-gathers/sec at 1440p, 1/2/4/8 GPUs; frame time (s)",
@@ -333,9 +375,9 @@ def main():
             "phases_ms_rank0": {**ph, "maps_enqueue_host_wall": t_maps / args.steps * 1e3,
                                 "map_global_emit": map_ms[0][0] / args.steps, "map_global_index": map_ms[0][1] / args.steps,
                                 "map_caustic_emit": map_ms[1][0] / args.steps, "map_caustic_index": map_ms[1][1] / args.steps},
-            "roofline": roof, "intersection": inter, "per_query_gather": per_query,
+            "roofline": roof, "roofline_all": roof_all, "intersection": inter, "per_query_gather": per_query,
         }
-        if not use_dist:
+        if not use_dist and not args.pmc_child:
             # the reference's boundary hands back a host pane (uint32 *pane of renderScene): the same step with the copy
             import numpy as _np
             host = _np.empty((args.height, args.width), dtype=_np.uint32)

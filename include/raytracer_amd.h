@@ -94,6 +94,10 @@ typedef struct pm_stats {
     /* with PM_FLAG_COUNT_TESTS: primitive intersection tests executed by the primary closest-hit pass and by the shadow any-hit pass
      * (a scene of 64 spheres or more is walked through the sphere grid: far fewer than rays x primitives) */
     uint64_t tests_primary_sphere, tests_primary_plane, tests_shadow_sphere, tests_shadow_plane;
+    /* the per-query kernel's share: shade points the group kernel of each map handed over (gathered by the per-query launch
+     * behind it, ms_gather_* - ms_group_*), and the bounced pixels' shade points that were never grouped (gathered by a
+     * per-query launch beside the group kernels, once per map) */
+    uint32_t left_global, left_caustic, early_points, reserved;
 } pm_stats;
 
 /* scheduler::startWorkers(int), src/JobSystem.cpp:76-86 (called at src/Main.cpp:34): `device` takes the place of `cores`.
@@ -104,6 +108,12 @@ int pm_ctx_destroy(pm_ctx *ctx);
 /* scheduler::waitForCompletion(), src/JobSystem.cpp:109-118: returns when everything the context has queued (the caller's
  * stream and the library's two build / gather streams) is done.  Unlike the reference's, the context stays usable. */
 int pm_ctx_synchronize(pm_ctx *ctx);
+/* Switches of a context that are no part of the reference's interface (it reads nothing at run time: its tunables are
+ * #defines, src/Raytrace.cpp:11-27).  "debug" (0 / 1): per-frame statistics on stderr; starts as 1 when PM_DEBUG is in the
+ * environment while the context is made -- the library reads the environment then and when a scene is uploaded, never per
+ * frame.  "sp_cap_limit" (slots, 0 = off; tests): pretend the shade point queue is this small, to show that a frame that
+ * overflows it is reported (PM_ESTATE), not delivered. */
+int pm_ctx_set_option(pm_ctx *ctx, const char *name, double value);
 /* Issue all work on this hipStream_t (NULL = the null stream). */
 int pm_ctx_set_stream(pm_ctx *ctx, void *hip_stream);
 const char *pm_last_error(void);
@@ -122,7 +132,8 @@ int pm_emit_range(pm_ctx *ctx, int32_t map_kind, uint64_t seed, const double lig
                   uint64_t *out_count);
 
 /* pm_emit_range without any allocation.  No counterpart in the reference: it is for callers that cannot call hipMalloc
- * (code under HIP graph capture, tight serving loops, harnesses that forbid it).  Same arguments, same records and count
+ * (tight serving loops, harnesses that forbid allocation).  It allocates nothing, but like pm_emit_range it WAITS for the
+ * stream to hand back *out_count, so it cannot be part of a HIP graph capture.  Same arguments, same records and count
  * as pm_emit_range, bit for bit; the kernels' scratch (attempt records, flags, block counts and offsets, 4.4 MB) is a
  * static device array that every GPU the library runs on holds until the process ends, so attempt_count is limited to
  * PM_EMIT_STATIC_MAX_ATTEMPTS (more: PM_EINVAL).  Calls on one GPU share that array: calls that overlap on one GPU race. */

@@ -43,7 +43,8 @@ class Stats(C.Structure):
                 ("ms_total", C.c_float), ("ms_gather", C.c_float), ("ms_group_global", C.c_float), ("ms_group_caustic", C.c_float),
                 ("grouped_global", C.c_uint32), ("grouped_caustic", C.c_uint32),
                 ("tests_primary_sphere", C.c_uint64), ("tests_primary_plane", C.c_uint64),
-                ("tests_shadow_sphere", C.c_uint64), ("tests_shadow_plane", C.c_uint64)]
+                ("tests_shadow_sphere", C.c_uint64), ("tests_shadow_plane", C.c_uint64),
+                ("left_global", C.c_uint32), ("left_caustic", C.c_uint32), ("early_points", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -53,7 +54,7 @@ class PMError(RuntimeError):
     pass
 
 
-EXPORTS = ["pm_ctx_create", "pm_ctx_destroy", "pm_ctx_set_stream", "pm_ctx_synchronize", "pm_last_error", "pm_scene_upload",
+EXPORTS = ["pm_ctx_create", "pm_ctx_destroy", "pm_ctx_set_option", "pm_ctx_set_stream", "pm_ctx_synchronize", "pm_last_error", "pm_scene_upload",
            "pm_emit_range", "pm_emit_range_static", "pm_emit_shard", "pm_map_build", "pm_map_build_shards", "pm_map_create", "pm_map_size", "pm_map_times", "pm_map_download", "pm_map_destroy",
            "pm_knn_query", "pm_knn_profile", "pm_knn_gather", "pm_primary_hits", "pm_intersect_rays", "pm_render",
            "pm_downsample", "pm_render_image"]
@@ -86,6 +87,7 @@ def load_library():
     vp, u64, i64, i32 = C.c_void_p, C.c_uint64, C.c_int64, C.c_int32
     sig = {
         "pm_ctx_create": [C.c_int, C.POINTER(vp)], "pm_ctx_destroy": [vp], "pm_ctx_set_stream": [vp, vp], "pm_ctx_synchronize": [vp],
+        "pm_ctx_set_option": [vp, C.c_char_p, C.c_double],
         "pm_scene_upload": [vp, vp, i32],
         "pm_emit_range": [vp, i32, u64, C.POINTER(C.c_double), u64, u64, vp, u64, C.POINTER(u64)],
         "pm_emit_range_static": [vp, i32, u64, C.POINTER(C.c_double), u64, u64, vp, u64, C.POINTER(u64)],
@@ -194,6 +196,10 @@ class Context:
 
     def synchronize(self):
         _check(self.lib.pm_ctx_synchronize(self.handle))
+
+    def set_option(self, name, value):
+        """Context switches outside the reference's interface: "debug" (0 / 1), "sp_cap_limit" (tests)."""
+        _check(self.lib.pm_ctx_set_option(self.handle, name.encode(), C.c_double(float(value))))
 
     def set_stream(self, stream_ptr):
         _check(self.lib.pm_ctx_set_stream(self.handle, C.c_void_p(stream_ptr)))

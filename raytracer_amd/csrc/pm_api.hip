@@ -108,6 +108,10 @@ struct pm_ctx {
     bool group_bounced = true; // PM_GROUP_BOUNCED=0: the bounced pixels' shade points stay with the per-query kernel (A/B switch)
     int tile_blocks = 0, query_blocks = 0, pair_blocks = 0;   // resident blocks of the gather kernels on this device
     bool use_pairs = true;     // PM_PAIR=0: the per-query gather takes one shade point per wave (k_gather) instead of two (k_gather_pair)
+    bool debug = false;        // PM_DEBUG in the environment when the context was made, or pm_ctx_set_option("debug"): per-frame statistics on stderr
+    long sp_cap_limit = 0;     // pm_ctx_set_option("sp_cap_limit") (tests): pretend the shade point queue is this small
+    hipEvent_t ev_frame = nullptr;   // the end of the latest frame on the caller's stream, behind the joins with the other two
+    unsigned long long frame_seq = 0, frame_waited = 0;   // frames queued; the latest one a host wait has covered
     uint32_t sp_cap = 0, c_cap = 0, b_cap = 0;   // slots of the shade point queue; node tables (bounced pixels); bounced pixels' shade points the spatial sort takes
     bool yield_known[2] = {false, false};        // a map of this scene and kind has reported what an emission attempt yields
     Counters *h_ctr = nullptr;   // pinned
@@ -134,6 +138,7 @@ struct pm_map {
     hipEvent_t ready = nullptr;
     hipEvent_t t_begin = nullptr, t_emitted = nullptr;   // on the build stream: emission starts / is over (the index build follows up to `ready`)
     uint64_t *h_got = nullptr;           // pinned, two words: photons available; a shard overflowed
+    unsigned long long used_in_frame = 0;   // the latest frame whose gathers read this map (pm_ctx::frame_seq); pm_map_destroy waits for it
     int kind = 0; uint64_t seed = 0, next_attempt = 0; double lc[3] = {0, 0, 0};
     DevBuf records, pos4, rest, cells, keys, cbox, grid;
     MapView view{};
@@ -153,6 +158,8 @@ static int ctx_init(pm_ctx *ctx) {
     for (int i = 0; i < 2; i++) HIPCHK(hipStreamCreateWithFlags(&ctx->slot[i].stream, hipStreamNonBlocking));
     ctx->aux = ctx->slot[0].stream; ctx->aux2 = ctx->slot[1].stream;
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_frame, hipEventDisableTiming));
+    ctx->debug = getenv("PM_DEBUG") != nullptr;      // (the environment is read here, once, not per frame)
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
@@ -190,6 +197,7 @@ extern "C" int pm_ctx_destroy(pm_ctx *ctx) {
     for (int i = 0; i < 2; i++) if (ctx->slot[i].stream) { (void)hipStreamSynchronize(ctx->slot[i].stream); (void)hipStreamDestroy(ctx->slot[i].stream); }
     for (int i = 0; i < 3; i++) ctx->slot[i].release();
     if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
+    if (ctx->ev_frame) (void)hipEventDestroy(ctx->ev_frame);
     DevBuf *bufs[] = {&ctx->scene, &ctx->sgrid, &ctx->geo, &ctx->obj, &ctx->pixel, &ctx->node, &ctx->tabslot, &ctx->direct, &ctx->radg, &ctx->radc,
                       &ctx->color, &ctx->clist, &ctx->tab, &ctx->ctr, &ctx->pane, &ctx->sample, &ctx->sched, &ctx->groups, &ctx->left, &ctx->strips,
                       &ctx->sp_keys_in, &ctx->sp_keys_out, &ctx->sp_vals_in, &ctx->sp_vals_out, &ctx->sp_sort_tmp, &ctx->sp_bounds, &ctx->sp_groups, &ctx->sp_early, &ctx->sp_pieces, &ctx->sp_loose};
@@ -213,6 +221,14 @@ extern "C" int pm_ctx_synchronize(pm_ctx *ctx) {
     PMCHK(set_device(ctx));
     for (int i = 0; i < 2; i++) if (ctx->slot[i].stream) HIPCHK(hipStreamSynchronize(ctx->slot[i].stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return PM_OK;
+}
+extern "C" int pm_ctx_set_option(pm_ctx *ctx, const char *name, double value) {
+    if (!ctx || !name) return fail(PM_EINVAL, "pm_ctx_set_option: NULL argument");
+    const std::string n(name);
+    if (n == "debug") ctx->debug = value != 0;
+    else if (n == "sp_cap_limit") { if (value < 0 || value > 4e9) return fail(PM_EINVAL, "pm_ctx_set_option: sp_cap_limit out of range"); ctx->sp_cap_limit = (long)value; }
+    else return fail(PM_EINVAL, "pm_ctx_set_option: unknown option '" + n + "' (debug, sp_cap_limit)");
     return PM_OK;
 }
 extern "C" int pm_ctx_set_stream(pm_ctx *ctx, void *hip_stream) {
@@ -386,7 +402,7 @@ extern "C" int pm_scene_upload(pm_ctx *ctx, const pm_prim *prims, int32_t n) {
         G.packed = reinterpret_cast<const double *>(gd + b_loose + b_start + b_refs);
         for (int a = 0; a < 3; a++) { G.lo[a] = hg.lo[a]; G.hi[a] = hg.hi[a]; G.cs[a] = hg.cs[a]; G.inv_cs[a] = 1.0 / hg.cs[a]; }
         ctx->scene_mode = SCENE_GRID;
-        if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] scene grid %d x %d x %d, %zu refs for %d spheres, %zu loose primitives\n", G.rx, G.ry, G.rz,
+        if (ctx->debug) fprintf(stderr, "[pm] scene grid %d x %d x %d, %zu refs for %d spheres, %zu loose primitives\n", G.rx, G.ry, G.rz,
                                         hg.refs.size(), nspheres, hg.loose.size());
     }
     if (const char *e = getenv("PM_SHADOW_PER_RAY")) ctx->shadow_per_ray = e[0] != '0';
@@ -486,9 +502,9 @@ extern "C" int pm_emit_range(pm_ctx *ctx, int32_t map_kind, uint64_t seed, const
     return emit_range(ctx, ctx->slot[2], map_kind, seed, light_color, attempt_begin, attempt_count, d_out, cap, ctx->h_u64, out_count);
 }
 
-// pm_emit_range for callers that cannot allocate (code under HIP graph capture, tight serving loops): the same kernels on
+// pm_emit_range for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc): the same kernels on
 // the static scratch array instead of the slot's hipMalloc'ed buffers.  No hipMalloc / hipFree / allocating routine is
-// called.  Every call on a GPU shares that GPU's array: a call overwrites all of the scratch it reads (flags, block counts,
+// called.  (Not for code under HIP graph capture: the call waits for the stream to learn the count.)  Every call on a GPU shares that GPU's array: a call overwrites all of the scratch it reads (flags, block counts,
 // offsets, records of its own attempts), so nothing has to be cleared, and two calls that overlap on one GPU race.
 extern "C" int pm_emit_range_static(pm_ctx *ctx, int32_t map_kind, uint64_t seed, const double light_color[3], uint64_t attempt_begin,
                                     uint64_t attempt_count, pm_photon *d_out, uint64_t cap, uint64_t *out_count) {
@@ -793,10 +809,13 @@ extern "C" int pm_map_destroy(pm_map *map) {
     if (ctx) {
         (void)hipSetDevice(ctx->device);
         if (map->pending) { (void)hipEventSynchronize(map->ready); map->pending = false; }   // its build may still be running
-        // and so may a gather that reads it: the caller's stream and the two streams beside it (a frame that ended in an error
-        // has already waited for them; this is for callers that destroy a map right behind an asynchronous use)
-        (void)hipStreamSynchronize(ctx->stream);
-        for (int i = 0; i < 2; i++) if (ctx->slot[i].stream) (void)hipStreamSynchronize(ctx->slot[i].stream);
+        // and so may the gathers of the latest frame that read it (a frame that ended in an error has already waited for
+        // them; this is for callers that destroy a map behind a frame they have not waited for): the end of that frame, no
+        // more -- the other map's build or a later frame may be queued on the same streams and are none of this map's business
+        if (map->used_in_frame > ctx->frame_waited) {
+            if (map->used_in_frame == ctx->frame_seq) { (void)hipEventSynchronize(ctx->ev_frame); ctx->frame_waited = ctx->frame_seq; }
+            else { (void)hipStreamSynchronize(ctx->stream); ctx->frame_waited = ctx->frame_seq; }   // (an older frame: its event has been recorded over)
+        }
     }
     // keep the buffers of up to four maps for the next ones (a frame rebuilds both maps; hipFree / hipMalloc of 100 MB cost more than the build)
     if (ctx && ctx->spare.size() < 4) { map->n = 0; memset(&map->view, 0, sizeof(map->view)); ctx->spare.push_back(map); }
@@ -1015,8 +1034,8 @@ static SPQueue sp_queue(pm_ctx *ctx) {
     q.rad_g = ctx->radg.as<double>(); q.rad_c = ctx->radc.as<double>(); q.color = ctx->color.as<uint32_t>();
     q.overflow = &ctx->ctr.as<Counters>()->overflow;
     q.cap = ctx->sp_cap;
-    // PM_SP_CAP_LIMIT (tests): pretend the queue is this small, to show that a frame that overflows it is reported, not delivered
-    if (const char *e = getenv("PM_SP_CAP_LIMIT")) { long v = atol(e); if (v > 0 && (uint32_t)v < q.cap) q.cap = (uint32_t)v; }
+    // option sp_cap_limit (tests): pretend the queue is this small, to show that a frame that overflows it is reported, not delivered
+    if (ctx->sp_cap_limit > 0 && (uint32_t)ctx->sp_cap_limit < q.cap) q.cap = (uint32_t)ctx->sp_cap_limit;
     return q;
 }
 
@@ -1045,7 +1064,7 @@ static int gather_blocks(pm_ctx *ctx) {
     if (const char *v = getenv("PM_TILE_PARTS")) { int x = atoi(v); if (x >= 1 && x <= 4) ctx->tile_parts = x; }
     if (const char *v = getenv("PM_LOOSE_TILES")) { double x = atof(v); if (x >= 0 && x < 1e6) { ctx->loose_tiles = x; ctx->loose_auto = false; } }
     if (const char *v = getenv("PM_SP_MIN_RUN")) { int x = atoi(v); if (x >= 1 && x <= 64) ctx->sp_min_run = x; }
-    if (getenv("PM_DEBUG")) fprintf(stderr, "[pm] resident gather blocks: group kernel %d (%d per CU), per-query kernel %d (%d per CU), %d CUs\n", ctx->tile_blocks, per_cu_t,
+    if (ctx->debug) fprintf(stderr, "[pm] resident gather blocks: group kernel %d (%d per CU), per-query kernel %d (%d per CU), %d CUs\n", ctx->tile_blocks, per_cu_t,
                                     ctx->query_blocks, per_cu_q, cus);
     return PM_OK;
 }
@@ -1114,7 +1133,7 @@ static int enqueue_frame(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
     uint32_t *sched = ctx->sched.as<uint32_t>();
     uint32_t *left = ctx->left.as<uint32_t>();
     const bool use_tiles = ctx->use_tiles;
-    const int dbg = getenv("PM_DEBUG") ? 1 : 0;
+    const int dbg = ctx->debug ? 1 : 0;
     // The shade points of bounced pixels (slots n_sp0 .. n_sp0 + n_bounced) in spatial order, for the group kernel; queued
     // before the wait for the maps, whose builds this overlaps.
     if (sort_bounced) {
@@ -1191,7 +1210,7 @@ static int enqueue_frame(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
             if (!gathered[kind]) continue;
             hipStream_t st = kind == 0 ? ctx->stream : ctx->aux;
             float4 *strips = ctx->strips.as<float4>() + (size_t)kind * ctx->tile_blocks * TS_STRIDE;
-            uint32_t *lk = left + ((size_t)kind * 4 + part) * q.cap, *nl = &d_ctr->n_left[kind][part];
+            uint32_t *lk = left + ((size_t)kind * nparts + part) * q.cap, *nl = &d_ctr->n_left[kind][part];
             if (use_tiles) {
                 uint32_t *sc = sched + (size_t)(n_sched++) * SCHED_WORDS;
                 if (kind == 0) hipLaunchKernelGGL(k_gather_tile<0>, dim3(ctx->tile_blocks), dim3(64), 0, st, map->view, q, ctx->groups.as<uint2>(), d_ctr, lk, nl, sc, strips, dbg,
@@ -1221,6 +1240,11 @@ static int enqueue_frame(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev[6], ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->h_ctr, d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, ctx->stream));
+    // the end of this frame, for pm_map_destroy: the caller's stream has joined the other two above
+    ctx->frame_seq++;
+    HIPCHK(hipEventRecord(ctx->ev_frame, ctx->stream));
+    if (gathered[0] && gmap) gmap->used_in_frame = ctx->frame_seq;
+    if (gathered[1] && cmap) cmap->used_in_frame = ctx->frame_seq;
     return PM_OK;
 }
 
@@ -1255,7 +1279,7 @@ static int render_impl(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_
     bool gathered[2] = {false, false};
     for (int attempt = 0;; attempt++) {
         PMCHK(ensure_sp(ctx, want_sp));
-        PMCHK(ctx->left.ensure((size_t)8 * ctx->sp_cap * 4 + 8));   // per map and part of the group launches
+        PMCHK(ctx->left.ensure((size_t)2 * ctx->tile_parts * ctx->sp_cap * 4 + 8));   // per map and part of the group launches
         PMCHK(ctx->sp_loose.ensure((size_t)ctx->sp_cap * 4));
         if (want_c > ctx->c_cap) { PMCHK(ctx->tab.ensure((size_t)want_c * 16 * sizeof(NodeEntry))); ctx->c_cap = want_c; }
         if (want_b > ctx->b_cap) {
@@ -1268,10 +1292,11 @@ static int render_impl(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_
         gathered[0] = gathered[1] = false;
         PMCHK(enqueue_frame(ctx, gmap, cmap, rp, fp, d_pane, owned, gathered));
         HIPCHK(hipStreamSynchronize(ctx->stream));
+        ctx->frame_waited = ctx->frame_seq;
         const Counters &hc = *ctx->h_ctr;
         bool again = false;
         if (hc.overflow) {
-            if (getenv("PM_SP_CAP_LIMIT") || attempt >= 3)
+            if (ctx->sp_cap_limit > 0 || attempt >= 3)
                 return fail(PM_ESTATE, "pm_render: the shade point queue overflowed (" + std::to_string(hc.n_sp) + " shade points): the pane is incomplete");
             if (hc.n_sp > 0xFFFFFF00u) return fail(PM_EINVAL, "pm_render: too many shade points for one call; split the frame over more ranks");
             // the counters kept counting past the capacities: they say what the frame needs
@@ -1314,7 +1339,7 @@ static int render_impl(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_
     const uint32_t n_sorted = sort_bounced ? hc.n_bounced : 0u, n_primary_sp = ctx->use_tiles ? n_sp0 + n_sorted : 0u;
     const int n_gathers = (gathered[0] ? 1 : 0) + (gathered[1] ? 1 : 0);
     Counters *d_ctr = ctx->ctr.as<Counters>();
-    if (getenv("PM_DEBUG")) {
+    if (ctx->debug) {
         fprintf(stderr, "[pm] shade points %u (primary %u), groups %u, left to the per-query gather: global %u caustic %u\n", n_sp, n_sp0,
                 hc.n_groups, left_of(hc, 0), left_of(hc, 1));
         fprintf(stderr, "[pm] shade points in spatial order: %u of bounced pixels + %u of spread-out tiles, in %u groups; %u straight to the per-query kernel\n", n_sorted,
@@ -1366,6 +1391,8 @@ static int render_impl(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_render_
             (void)hipEventElapsedTime(&stats->ms_group_caustic, ctx->ev_g[1][0], ctx->ev_g[1][1]);
             stats->grouped_caustic = n_primary_sp ? n_primary_sp - left_of(hc, 1) - hc.n_early : 0u;
         }
+        stats->left_global = gathered[0] ? left_of(hc, 0) : 0u; stats->left_caustic = gathered[1] ? left_of(hc, 1) : 0u;
+        stats->early_points = ctx->use_tiles ? (sort_bounced ? hc.n_early : hc.n_bounced) : 0u;
         (void)hipEventElapsedTime(&stats->ms_resolve, ctx->ev[5], ctx->ev[6]);
         (void)hipEventElapsedTime(&stats->ms_total, ctx->ev[0], ctx->ev[6]);
     }

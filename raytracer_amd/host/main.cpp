@@ -10,7 +10,7 @@
 //   --out FILE    image file (default raytraced.png, the reference's name)
 //   --scene WHAT  a scene other than the reference's Cornell box: a scene file (raytrace::loadScene: `*.bin` = pm_prim
 //                 records, else text), `caustics` (BASELINE config 4), `spheres:N[:SEED]` (config 5: the walls + N spheres)
-//   --rank R --world N --id-file PATH
+//   --rank R --world N --id-file PATH [--token T]
 //                 one process per GPU (raytrace_dist.h): this process is rank R of N, each started with its own GPU visible
 //                 (HIP_VISIBLE_DEVICES); rank 0 writes RCCL's unique id to PATH, the others wait for it; rank 0 writes the
 //                 image.  Also RANK / WORLD_SIZE from the environment when --id-file is given.
@@ -50,7 +50,7 @@ bool parse(int argc, char *argv[], Options &o, std::vector<const char *> &positi
     if (const char *e = std::getenv("RAYTRACER_PHOTONS")) o.photons = std::atoll(e);
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
-        const bool wants_value = a == "--photons" || a == "--seed" || a == "--out" || a == "--scene" || a == "--rank" || a == "--world" || a == "--id-file";
+        const bool wants_value = a == "--photons" || a == "--seed" || a == "--out" || a == "--scene" || a == "--rank" || a == "--world" || a == "--id-file" || a == "--token";
         if (!wants_value) { positional.push_back(argv[i]); continue; }
         if (i + 1 >= argc) return false;
         const char *v = argv[++i];
@@ -60,6 +60,7 @@ bool parse(int argc, char *argv[], Options &o, std::vector<const char *> &positi
         else if (a == "--rank") o.rank = std::atoi(v);
         else if (a == "--world") o.world = std::atoi(v);
         else if (a == "--id-file") o.id_file = v;
+        else if (a == "--token") setenv("RAYTRACER_GROUP_TOKEN", v, 1);     // what tells this launch's id file from a stale one (raytrace_dist.cpp)
         else o.out = v;
     }
     if (!o.id_file.empty() && o.world == 0) {
@@ -83,6 +84,17 @@ int main(int argc, char *argv[]) {
     o.width = std::atoi(pos[1]); o.height = std::atoi(pos[2]); o.samples = std::atoi(pos[3]);
     for (const Refusal &r : kRefusals)
         if (r.applies(o)) { std::fputs(r.message, stdout); return 0; }
+    // an option of ours that cannot work is NOT one of the reference's refusals (those print to stdout and return 0): it goes
+    // to stderr with a non-zero exit code, so that a launcher can tell it from a frame that was rendered; checked before
+    // anything touches the GPU
+    long spheres_n = 0;
+    unsigned long long spheres_seed = 2024ULL;
+    if (o.scene.rfind("spheres:", 0) == 0) {
+        char *end = nullptr;
+        spheres_n = std::strtol(o.scene.c_str() + 8, &end, 10);
+        if (end && *end == ':') spheres_seed = std::strtoull(end + 1, nullptr, 10);
+        if (end == o.scene.c_str() + 8 || spheres_n < 0 || spheres_n > (1 << 22)) { std::fputs("--scene spheres:N needs 0 <= N <= 4194304\n", stderr); return 2; }
+    }
     if (o.have_seed) randutil::init(o.seed);
     if (o.photons >= 0) raytrace::setPhotonCounts((int32)o.photons, (int32)o.photons);
     scheduler::startWorkers(o.cores);          // opens the GPU context; `cores` has no other meaning here
@@ -90,11 +102,7 @@ int main(int argc, char *argv[]) {
     if (!o.scene.empty()) {
         if (o.scene == "caustics") scene = raytrace::causticsScene();
         else if (o.scene.rfind("spheres:", 0) == 0) {
-            char *end = nullptr;
-            const long n = std::strtol(o.scene.c_str() + 8, &end, 10);
-            const unsigned long long seed = (end && *end == ':') ? std::strtoull(end + 1, nullptr, 10) : 2024ULL;
-            if (n < 0 || n > (1 << 22)) { std::fputs("--scene spheres:N needs 0 <= N <= 4194304\n", stdout); return 0; }
-            scene = raytrace::manySpheresScene((int32)n, seed);
+            scene = raytrace::manySpheresScene((int32)spheres_n, spheres_seed);
         } else if (!(scene = raytrace::loadScene(o.scene.c_str()))) return 1;
     }
     if (o.world > 0) {

@@ -98,8 +98,14 @@ bool SceneObject::intersect(Vec3 *ray_source, Vec3 *ray, Vec3 *result, Vec3 *res
     int32_t at = -1;
     for (size_t i = 0; i < g_uploaded.size() && at < 0; i++)
         if (std::memcmp(&g_uploaded[i], &me, sizeof(me)) == 0) at = (int32_t)i;
-    if (at < 0) { upload(std::vector<pm_prim>(1, me)); at = 0; }   // an object on its own: a scene of one
-    return one_ray(ray_source, ray, dt, at, -1, result, result_normal) != 0;
+    if (at >= 0) return one_ray(ray_source, ray, dt, at, -1, result, result_normal) != 0;
+    // an object on its own: a scene of one for the length of this call, then the scene the GPU held before (with its sphere
+    // grid and what the library has learnt about it) is put back
+    const std::vector<pm_prim> before = g_uploaded;
+    upload(std::vector<pm_prim>(1, me));
+    const bool hit = one_ray(ray_source, ray, dt, 0, -1, result, result_normal) != 0;
+    if (!before.empty()) upload(before);
+    return hit;
 }
 
 void Scene::intersect(Vec3 &ray_source, Vec3 &ray, SceneObject *exclude, Vec3 *result, Vec3 *result_normal, SceneObject **hit_object, double dt) {

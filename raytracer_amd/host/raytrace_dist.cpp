@@ -60,21 +60,31 @@ RankGroup *joinRanks(int32 rank, int32 world, const char *id_file) {
     pm_ctx *ctx = backend::context();            // before RCCL: the library's streams get hardware queues of their own
     hip_ok(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking), "hipStreamCreate");
     backend::checked(pm_ctx_set_stream(ctx, g->stream), "pm_ctx_set_stream");
+    // RCCL's unique id travels through a file: {token, id}.  The token (RAYTRACER_GROUP_TOKEN, or --token of the CLI: any
+    // number the launcher gives every rank of ONE launch, e.g. its own pid) tells this launch's file from one that a rank 0
+    // which died left behind: the other ranks wait for a file with THEIR token instead of taking a stale id and hanging in
+    // ncclCommInitRank.  Without a token (0) any file is taken, as before: the launcher then has to remove stale files itself.
+    unsigned long long token = 0;
+    if (const char *e = std::getenv("RAYTRACER_GROUP_TOKEN")) token = std::strtoull(e, nullptr, 0);
+    struct IdRecord { unsigned long long token; ncclUniqueId id; } rec;
+    std::memset(&rec, 0, sizeof(rec));
     ncclUniqueId id;
     if (rank == 0) {
         nccl_ok(ncclGetUniqueId(&id), "ncclGetUniqueId");
+        rec.token = token; rec.id = id;
         const std::string tmp = std::string(id_file) + ".tmp";
         FILE *f = std::fopen(tmp.c_str(), "wb");
-        if (!f || std::fwrite(&id, sizeof(id), 1, f) != 1) { std::fprintf(stderr, "raytracer_amd: cannot write %s\n", tmp.c_str()); std::abort(); }
+        if (!f || std::fwrite(&rec, sizeof(rec), 1, f) != 1) { std::fprintf(stderr, "raytracer_amd: cannot write %s\n", tmp.c_str()); std::abort(); }
         std::fclose(f);
         if (std::rename(tmp.c_str(), id_file) != 0) { std::fprintf(stderr, "raytracer_amd: cannot create %s\n", id_file); std::abort(); }
     } else {
         bool got = false;
         for (int tries = 0; tries < 1200 && !got; tries++) {      // up to two minutes for rank 0 to come up
-            if (FILE *f = std::fopen(id_file, "rb")) { got = std::fread(&id, sizeof(id), 1, f) == 1; std::fclose(f); }
+            if (FILE *f = std::fopen(id_file, "rb")) { got = std::fread(&rec, sizeof(rec), 1, f) == 1 && rec.token == token; std::fclose(f); }
             if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(100));
         }
-        if (!got) { std::fprintf(stderr, "raytracer_amd: rank %d never saw %s\n", rank, id_file); std::abort(); }
+        if (!got) { std::fprintf(stderr, "raytracer_amd: rank %d never saw %s with this launch's token\n", rank, id_file); std::abort(); }
+        id = rec.id;
     }
     nccl_ok(ncclCommInitRank(&g->comm, world, id, rank), "ncclCommInitRank");
     return g;

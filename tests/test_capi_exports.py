@@ -32,7 +32,7 @@ def test_header_symbols_are_exported():
 def test_struct_layouts():
     assert ra.prim_dtype.itemsize == 144 and ra.photon_dtype.itemsize == 32
     assert ctypes.sizeof(ra.RenderParams) == 80
-    assert ctypes.sizeof(ra.Stats) == 120
+    assert ctypes.sizeof(ra.Stats) == 136
     assert ra.photon_dtype.fields["power"][1] == 12 and ra.photon_dtype.fields["dx"][1] == 16 and ra.photon_dtype.fields["bounce"][1] == 28
 
 

@@ -1,6 +1,6 @@
 """CPU tests of the N > 1 path: attempt-range sharding + all-gather assembly of the photon map and the
 interleaved row-block gather of the pane, with the oracle standing in for the GPU kernels.  The
-multi-process tests run the product's own collective helpers (raytracer_amd.frame) on gloo, world 2."""
+multi-process tests run the product's own collective helpers (raytracer_amd.frame) on gloo, world 2 and world 8."""
 import os
 import socket
 
@@ -63,6 +63,11 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+def _row_marks(h, w):
+    y, x = np.mgrid[0:h, 0:w]
+    return ((y.astype(np.uint64) * 2654435761 + x.astype(np.uint64) * 40503) & 0xFFFFFFFF).astype(np.uint32)
+
+
 def _worker(rank, world, port, w, h, n, seed, q):
     import torch
     import torch.distributed as dist
@@ -85,23 +90,31 @@ def _worker(rank, world, port, w, h, n, seed, q):
     for b in frame.owned_row_blocks(h, rank, world):
         orc.render(scene, g, c, rp, y0=b * 16, y1=min(h, b * 16 + 16), pane=pane)
     full = frame.gather_row_blocks(dist, torch.from_numpy(pane.view(np.int32)), rank, world)
+    # the same gather on a pane whose every row is different (most rows of a tall frame miss the scene and are one colour):
+    # a row block that landed in the wrong place would show here
+    marks = np.zeros((h, w), dtype=np.uint32)
+    for b in frame.owned_row_blocks(h, rank, world):
+        marks[b * 16:min(h, b * 16 + 16)] = _row_marks(h, w)[b * 16:min(h, b * 16 + 16)]
+    full_marks = frame.gather_row_blocks(dist, torch.from_numpy(marks.view(np.int32)), rank, world)
     if rank == 0:
-        q.put((maps[0].tobytes(), maps[1].tobytes(), full.numpy().view(np.uint32).copy()))
+        q.put((maps[0].tobytes(), maps[1].tobytes(), full.numpy().view(np.uint32).copy(), full_marks.numpy().view(np.uint32).copy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_frame_equals_single_rank(orc):
-    """gloo, world_size 2: photon maps and the gathered pane are identical to the 1-rank result."""
+@pytest.mark.parametrize("world,w,h", [(2, 96, 70),        # 70 rows: 5 row blocks, the last one partial, uneven split
+                                       (8, 128, 1440)])    # the bench frame's 1440 rows: 90 row blocks over 8 ranks, 11 or 12 each
+def test_multi_rank_frame_equals_single_rank(orc, world, w, h):
+    """gloo, world_size 2 and 8: photon maps and the gathered pane are identical to the 1-rank result."""
     import torch.multiprocessing as mp
-    w, h, n, seed = 96, 70, 1500, 7     # 70 rows: 5 row blocks, the last one partial, uneven split
+    n, seed = 1500, 7
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, w, h, n, seed, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, w, h, n, seed, q)) for r in range(world)]
     for p in procs:
         p.start()
-    g_bytes, c_bytes, pane = q.get(timeout=240)
+    g_bytes, c_bytes, pane, marks = q.get(timeout=400)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -112,4 +125,5 @@ def test_two_rank_frame_equals_single_rank(orc):
     g, c = orc.Map(wg), orc.Map(wc)
     want, _ = orc.render(scene, g, c, orc.params(w, h, seed), nthreads=4)
     assert np.array_equal(pane, want)
+    assert np.array_equal(marks, _row_marks(h, w))
     g.close(); c.close()

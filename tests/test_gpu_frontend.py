@@ -118,10 +118,10 @@ def test_a_frame_that_overflows_its_queue_is_reported(gpu_ctx, monkeypatch):
     g = gpu_ctx.create_map(0, 2048, 1); c = gpu_ctx.create_map(1, 2048, 1)
     rp = gpu_ctx.params(320, 200, 1)
     good, _ = gpu_ctx.render(g, c, rp)
-    monkeypatch.setenv("PM_SP_CAP_LIMIT", "1000")             # far fewer slots than the frame has shade points
+    gpu_ctx.set_option("sp_cap_limit", 1000)                  # far fewer slots than the frame has shade points
     with pytest.raises(ra.PMError, match="shade point queue overflowed"):
         gpu_ctx.render(g, c, rp)
-    monkeypatch.delenv("PM_SP_CAP_LIMIT")
+    gpu_ctx.set_option("sp_cap_limit", 0)
     again, _ = gpu_ctx.render(g, c, rp)                       # and the context is fine afterwards
     assert np.array_equal(good, again)
     g.destroy(); c.destroy()
@@ -138,10 +138,10 @@ def test_an_overflowing_frame_with_spread_out_tiles(monkeypatch):
         g = ctx.create_map(0, 4096, 1); c = ctx.create_map(1, 4096, 1)
         rp = ctx.params(320, 200, 1)
         good, _ = ctx.render(g, c, rp)
-        monkeypatch.setenv("PM_SP_CAP_LIMIT", "1500")
+        ctx.set_option("sp_cap_limit", 1500)
         with pytest.raises(ra.PMError, match="shade point queue overflowed"):
             ctx.render(g, c, rp)
-        monkeypatch.delenv("PM_SP_CAP_LIMIT")
+        ctx.set_option("sp_cap_limit", 0)
         again, _ = ctx.render(g, c, rp)
         assert np.array_equal(good, again)
         g.destroy(); c.destroy()

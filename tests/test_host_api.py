@@ -186,10 +186,12 @@ def test_cli_renders_a_scene_file(tmp_path, orc, scene, samples):
 def _run_ranks(tmp_path, world, args, env, out_name):
     """One raytracer process per rank, all started at once (one process per GPU: rank r sees GPU r as device 0)."""
     id_file = tmp_path / f"rccl_id_{out_name}"
+    id_file.write_bytes(b"\x01" * 136)       # what a rank 0 that died would have left: token 0x0101..., not ours
     procs = []
     for r in range(world):
         e = dict(env, HIP_VISIBLE_DEVICES=str(r)) if world > 1 else dict(env)
-        procs.append(subprocess.Popen([EXE, "--rank", str(r), "--world", str(world), "--id-file", str(id_file), "--out", out_name] + args,
+        # (the token tells this launch's id file from one a dead rank 0 left behind; a stale file with another token is waiting there)
+        procs.append(subprocess.Popen([EXE, "--rank", str(r), "--world", str(world), "--id-file", str(id_file), "--token", str(os.getpid()), "--out", out_name] + args,
                                       cwd=tmp_path, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=300) for p in procs]
     for p, (so, se) in zip(procs, outs):

@@ -31,6 +31,10 @@ def test_cli_argument_checks(tmp_path):
     r = run(["--photons", 10, "--out", "x.png", 8, 1440, 1440, 1], tmp_path)
     assert r.returncode == 0 and r.stdout == "Image dimensions must be a 16:9 ratio.\n"
     assert not os.path.exists(tmp_path / "raytraced.png") and not os.path.exists(tmp_path / "x.png")
+    # an option of ours that cannot work is an error a launcher can see: stderr, non-zero, before the GPU is touched
+    for bad in ("spheres:-3", "spheres:99999999", "spheres:x"):
+        r = run(["--scene", bad, 8, 1280, 720, 1], tmp_path)
+        assert r.returncode == 2 and r.stdout == "" and "spheres:N" in r.stderr
 
 
 @pytest.mark.gpu

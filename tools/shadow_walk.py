@@ -13,7 +13,7 @@ frame = GpuFrame(ctx, 1440, 1440, 1000000, 12345)
 for _ in range(2):
     frame.step()
 torch.cuda.synchronize()
-os.environ.pop("PM_DEBUG")
+ctx.set_option("debug", 0)
 ms = []
 for _ in range(5):
     frame.build_maps(); st = frame.render(); ms.append((st.ms_primary, st.ms_secondary, st.ms_shadow, st.ms_total))
@@ -42,7 +42,7 @@ ms = []
 for _ in range(5):
     st = frame.render(); ms.append((st.ms_primary, st.ms_secondary, st.ms_shadow, st.ms_total))
 print("alone (maps kept) ms primary/secondary/shadow/total:", [tuple(round(x, 3) for x in m) for m in ms])
-os.environ["PM_DEBUG"] = "1"
+ctx.set_option("debug", 1)
 frame.flags |= ra.PM_FLAG_COUNT_TESTS
 st = frame.render()
 print("tests primary", st.tests_primary_sphere, st.tests_primary_plane, "shadow", st.tests_shadow_sphere, st.tests_shadow_plane, "sp", st.absorb_points)
