@@ -31,7 +31,7 @@ struct FrameParams {
     int rank, world;
 };
 
-struct Counters { uint32_t n_sp, n_complex, n_secondary, n_groups, n_left[2][4], pad, n_sgroups, n_early, n_pieces, overflow, n_sp0, n_bounced, done_primary, done_secondary, n_loose, n_sorted; unsigned long long tests[4]; unsigned long long walk[4]; uint32_t why[8]; unsigned long long tphase[8]; uint32_t ghist[2][32]; };   // n_left[k][p]: shade points that part p of map k's group launches left to the per-query gather
+struct Counters { uint32_t n_sp, n_groups, n_complex, n_secondary, n_left[2][4], pad, n_sgroups, n_early, n_pieces, overflow, n_sp0, n_bounced, done_primary, done_secondary, n_loose, n_sorted; unsigned long long tests[4]; unsigned long long walk[4]; uint32_t why[8]; unsigned long long tphase[8]; uint32_t ghist[2][32]; };   // n_left[k][p]: shade points that part p of map k's group launches left to the per-query gather; n_sp and n_groups are one 64-bit word for k_primary (one atomic per block takes slots and group entries together)
 
 // The frame's counts live on the device: nothing of a frame waits for the host.  n_sp0 = shade points of primary hits (slots
 // 0 .. n_sp0, grouped by pixel tile), written by k_mark_primary behind k_primary; n_bounced = shade points of bounced pixels
@@ -132,34 +132,50 @@ __device__ inline void primary_body(const SceneView &gs, const FrameParams &fp, 
         else if (sv.f(G_ABSORB, obj) > 0) emit_sp = true;
         else pane[pixel] = mix_colour(0, 0, 0, sv.f(G_SPECULAR, obj), sv.f(G_TRANSMISSION, obj), sv.f(G_ABSORB, obj));
     }
-    // wavefront-ballot compaction: one atomic per wave and queue
+    // wavefront-ballot compaction, one atomic per BLOCK for the shade point slots and the group entries of its four tiles
+    // together ({n_sp, n_groups} is one 64-bit word): an atomic per wave and counter -- 16 000 on one cache line at 1440 x 1440,
+    // a quarter of a million at 7680 x 4320 -- was what the pass waited for
+    __shared__ uint32_t blk_cnt[4], blk_grp[4], blk_cx[4], blk_cx_base;
+    __shared__ unsigned long long blk_base;
+    const int wave = threadIdx.x >> 6;
     unsigned long long m = __ballot(emit_sp);
+    const uint32_t count = (uint32_t)__popcll(m);
+    bool spread = false;
+    if (m && loose_k > 0) {
+        const double d2 = (res.x - fp.cam.x) * (res.x - fp.cam.x) + (res.y - fp.cam.y) * (res.y - fp.cam.y) + (res.z - fp.cam.z) * (res.z - fp.cam.z);
+        const double near2 = wave_min_f64(emit_sp ? d2 : 1e300), far2 = wave_max_f64(emit_sp ? d2 : 0.0);
+        spread = far2 > near2 * loose_k;
+    }
+    const unsigned long long mcx = __ballot(emit_cx);
+    if (lane == 0) { blk_cnt[wave] = count; blk_grp[wave] = count && !spread ? 1u : 0u; blk_cx[wave] = (uint32_t)__popcll(mcx); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = blk_cnt[0] + blk_cnt[1] + blk_cnt[2] + blk_cnt[3], ng = blk_grp[0] + blk_grp[1] + blk_grp[2] + blk_grp[3];
+        blk_base = total ? atomicAdd(reinterpret_cast<unsigned long long *>(&ctr->n_sp), (unsigned long long)total | ((unsigned long long)ng << 32)) : 0ULL;
+    }
+    if (threadIdx.x == 64) {
+        const uint32_t total = blk_cx[0] + blk_cx[1] + blk_cx[2] + blk_cx[3];
+        blk_cx_base = total ? atomicAdd(&ctr->n_complex, total) : 0u;
+    }
+    __syncthreads();
     if (m) {
-        int leader = __ffsll((long long)m) - 1;
-        bool spread = false;
-        if (loose_k > 0) {
-            const double d2 = (res.x - fp.cam.x) * (res.x - fp.cam.x) + (res.y - fp.cam.y) * (res.y - fp.cam.y) + (res.z - fp.cam.z) * (res.z - fp.cam.z);
-            const double near2 = wave_min_f64(emit_sp ? d2 : 1e300), far2 = wave_max_f64(emit_sp ? d2 : 0.0);
-            spread = far2 > near2 * loose_k;
-        }
-        uint32_t base = 0, lbase = 0;
+        uint32_t base = (uint32_t)blk_base, gslot = (uint32_t)(blk_base >> 32);
+        for (int w = 0; w < wave; w++) { base += blk_cnt[w]; gslot += blk_grp[w]; }
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t lbase = 0;
         if (lane == leader) {
-            base = atomicAdd(&ctr->n_sp, (uint32_t)__popcll(m));
-            if (spread) lbase = atomicAdd(&ctr->n_loose, (uint32_t)__popcll(m));
-            else groups[atomicAdd(&ctr->n_groups, 1u)] = make_uint2(base, (uint32_t)__popcll(m));   // the tile's shade points: one gather group
+            if (spread) lbase = atomicAdd(&ctr->n_loose, count);
+            else groups[gslot] = make_uint2(base, count);   // the tile's shade points: one gather group
         }
-        base = __shfl(base, leader); lbase = __shfl(lbase, leader);
+        lbase = __shfl(lbase, leader);
         const uint32_t rank = (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL));
         if (emit_sp) sp_store(q, base + rank, res, nrm, obj, pixel, 1u, 0u);
         if (emit_sp && spread && lbase + rank < q.cap) loose[lbase + rank] = base + rank;
     }
-    m = __ballot(emit_cx);
-    if (m) {
-        int leader = __ffsll((long long)m) - 1;
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&ctr->n_complex, (uint32_t)__popcll(m));
-        base = __shfl(base, leader);
-        if (emit_cx) complex_list[base + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL))] = pixel;
+    if (emit_cx) {
+        uint32_t base = blk_cx_base;
+        for (int w = 0; w < wave; w++) base += blk_cx[w];
+        complex_list[base + (uint32_t)__popcll(mcx & ((1ULL << lane) - 1ULL))] = pixel;
     }
     if (COUNT) { wave_add_count(&ctr->tests[0], tc.spheres); wave_add_count(&ctr->tests[1], tc.planes); }
 }
@@ -281,7 +297,12 @@ __global__ __launch_bounds__(256) void k_secondary(SceneView gs, FrameParams fp,
                 } else {
                     uint32_t slot = 0xFFFFFFFFu;
                     if (sv.f(G_ABSORB, obj) > 0) {          // absorb branch is evaluated later, from the queue
-                        slot = atomicAdd(&ctr->n_sp, 1u);
+                        // (the lanes that are here together take their slots with one atomic)
+                        const unsigned long long here = __ballot(true);
+                        const int first = __ffsll((long long)here) - 1;
+                        uint32_t base = 0;
+                        if ((int)(threadIdx.x & 63) == first) base = atomicAdd(&ctr->n_sp, (uint32_t)__popcll(here));
+                        slot = (uint32_t)__shfl((int)base, first) + (uint32_t)__popcll(here & ((1ULL << (threadIdx.x & 63)) - 1ULL));
                         sp_store(q, slot, f.hit, f.nrm, obj, pixel, node | NODE_COMPLEX, c * 16 + node);
                     }
                     my[node].a = 2u | ((uint32_t)obj << 8);
@@ -292,7 +313,8 @@ __global__ __launch_bounds__(256) void k_secondary(SceneView gs, FrameParams fp,
             if (depth < 0) break;
         }
     }
-    if (nsec) atomicAdd(&ctr->n_secondary, nsec);
+    for (int sh = 1; sh < 64; sh <<= 1) nsec += (uint32_t)__shfl_xor((int)nsec, sh);
+    if ((threadIdx.x & 63) == 0 && nsec) atomicAdd(&ctr->n_secondary, nsec);
 }
 
 // shadow loop + direct term, src/Raytrace.cpp:174-212
