@@ -604,7 +604,7 @@ __global__ __launch_bounds__(256) void k_gather(MapView m_in, SPQueue q, const u
 // right here.  The kernel the frame uses (PM_PAIR=0: k_gather, for A/B runs).
 template <int KIND>
 #ifndef PM_PAIR_WAVES
-#define PM_PAIR_WAVES 3
+#define PM_PAIR_WAVES 4
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM_PAIR_WAVES, PM_PAIR_WAVES))) void k_gather_pair(MapView m_in, SPQueue q, const uint32_t *left, const uint32_t *n_left, const Counters *ctr, int sec_mode,
                                                      uint32_t *sched) {
