@@ -525,7 +525,10 @@ __device__ __noinline__ uint32_t wave_draw(uint32_t *ctr) {
 #ifndef PM_GATHER_GROUP
 #define PM_GATHER_GROUP 2      // consecutive shade points (neighbours) per draw: the second starts from the first one's ball
 #endif
-constexpr uint32_t SCHED_CHUNK = 1024;   // items per chunk; chunk c belongs to counter c % 64
+#ifndef PM_SCHED_CHUNK
+#define PM_SCHED_CHUNK 256
+#endif
+constexpr uint32_t SCHED_CHUNK = PM_SCHED_CHUNK;   // items per chunk; chunk c belongs to counter c % 64
 constexpr uint32_t SCHED_STRIDE = 32;    // one counter per 128-byte line
 constexpr uint32_t SCHED_WORDS = 64 * SCHED_STRIDE;
 static_assert(SCHED_CHUNK % PM_GATHER_GROUP == 0, "a draw must not straddle two chunks");
@@ -534,15 +537,20 @@ static_assert(SCHED_CHUNK % PM_GATHER_GROUP == 0, "a draw must not straddle two 
 // k % 8 (blocks b, b+8, ... share an XCD and its L2).  A wave starts on one of its XCD's 8 counters and moves to the next
 // when that runs dry, so a cluster of expensive items never becomes one wave's tail and no counter sees more than a few
 // thousand draws.  Returns false when all 8 counters are exhausted; else [i0, i1) is a run of up to `group` items.
+// Chunk sizes (round 3): an XCD never draws from another XCD's counters, so with chunks of 1 024 groups a 1440 x 1440 frame
+// (8 126 groups) gave every XCD ONE strip of the image, and the strips differ in cost by up to 60 % (a group of the caustic
+// map: 221 us in the top strip, 138 us in the seventh).  128 groups per chunk (PM_TILE_CHUNK) deals eight strips to every
+// XCD: default scene 2.23 -> 2.19 ms per step, five glass spheres 2.63 -> 2.53, config 3's sizes 35.0 -> 34.6; 256 items for
+// the per-query kernels (PM_SCHED_CHUNK) another 0.01.  32 groups per chunk is slower again (an XCD's L2 then sees the whole map).
 struct WorkDraw {
     uint32_t xcd, sub, tries;
     __device__ WorkDraw() : xcd(blockIdx.x & 7), sub((blockIdx.x >> 3) & 7), tries(0) {}
-    __device__ bool next(uint32_t *sched, uint32_t n_items, uint32_t group, uint32_t &i0, uint32_t &i1) {   // items 0 .. n_items
+    __device__ bool next(uint32_t *sched, uint32_t n_items, uint32_t group, uint32_t &i0, uint32_t &i1, const uint32_t chunk = SCHED_CHUNK) {   // items 0 .. n_items
         while (tries < 8) {
             const uint32_t c = xcd + 8 * sub;
             uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_draw(&sched[c * SCHED_STRIDE]));
             uint32_t li = g * group;
-            uint64_t s0 = ((uint64_t)c + 64ull * (li / SCHED_CHUNK)) * SCHED_CHUNK + li % SCHED_CHUNK;
+            uint64_t s0 = ((uint64_t)c + 64ull * (li / chunk)) * chunk + li % chunk;
             if (s0 >= n_items) { tries++; sub = (sub + 1) & 7; continue; }   // this counter is exhausted (s0 grows with every draw)
             i0 = (uint32_t)s0;
             i1 = i0 + group < n_items ? i0 + group : n_items;
@@ -668,6 +676,9 @@ static __device__ uint32_t g_tile_groups[2][16384][2];     // per group {start, 
 #ifndef PM_TILE_WAVES
 #define PM_TILE_WAVES 4
 #endif
+#ifndef PM_TILE_CHUNK
+#define PM_TILE_CHUNK 128
+#endif
 // One wave per GROUP of shade points (pm_tile.h): the shade points of one 8x8 pixel tile, one per lane.  A group that
 // cannot be gathered as a group appends its slots to `left` for k_gather.
 template <int KIND>
@@ -691,7 +702,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PM_TILE_WAVE
     uint32_t wgroups = 0;
     if (lane == 0 && blockIdx.x < 8192) { uint32_t *o = g_tile_waves[KIND][blockIdx.x]; o[0] = (uint32_t)wt0; o[1] = (uint32_t)wt0; o[2] = 0; o[3] = wd.xcd | ((uint32_t)__builtin_amdgcn_s_getreg(20 | (3 << 11)) << 8); }   // (hardware register 20: XCC_ID, 4 bits)
 #endif
-    while (wd.next(sched, g_hi - g_lo, 1u, i0, i1)) {
+    while (wd.next(sched, g_hi - g_lo, 1u, i0, i1, (uint32_t)PM_TILE_CHUNK)) {
         i0 += g_lo;
 #ifdef PM_WAVE_TIMES
         const uint32_t gt0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
