@@ -505,7 +505,13 @@ __device__ inline void shadow_rays_body(const SceneView &gs, const FrameParams &
     if (COUNT) { wave_add_count(&ctr->tests[2], tc.spheres); wave_add_count(&ctr->tests[3], tc.planes); wave_add_count(&ctr->walk[0], tc.cells); wave_add_count(&ctr->walk[1], tc.wsteps); wave_add_count(&ctr->walk[2], tc.wtests); }
 }
 template <int MODE>
-__global__ __launch_bounds__(256) void k_shadow_rays(SceneView gs, FrameParams fp, SPQueue q, Counters *ctr) { shadow_rays_body<MODE, false, true>(gs, fp, q, ctr); }
+// (through the sphere grid the pass waits for memory 47 % of its wave cycles: at least six waves per SIMD -- 80 VGPRs, 10 dwords of
+// scratch per lane, and as many as the tracer's 25 KB of LDS per block allow -- 7.28 -> 7.09 ms per step on 10 000 spheres; the
+// passes of small scenes need 52 registers and are not affected)
+#ifndef PM_SHADOW_WAVES
+#define PM_SHADOW_WAVES 6
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM_SHADOW_WAVES))) void k_shadow_rays(SceneView gs, FrameParams fp, SPQueue q, Counters *ctr) { shadow_rays_body<MODE, false, true>(gs, fp, q, ctr); }
 template <int MODE>
 __global__ __launch_bounds__(256) void k_shadow_rays_count(SceneView gs, FrameParams fp, SPQueue q, Counters *ctr) { shadow_rays_body<MODE, true, true>(gs, fp, q, ctr); }
 // every ray walks and tests on its own (PM_SHADOW_QUEUE=0: A/B runs of the sphere grid's walk)

@@ -9,18 +9,30 @@ lib = ra.load_library()
 ctx = ra.Context(0)
 scene = {"default": ra.default_scene, "spheres10k": ra.many_spheres_scene, "caustics": ra.caustics_scene}[sys.argv[1] if len(sys.argv) > 1 else "default"]()
 ctx.upload_scene(scene)
-frame = GpuFrame(ctx, 1440, 1440, 1000000, 12345)
+world = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # > 1: rank 0's share of the row blocks of a world of that size
+if world == 1:
+    frame = GpuFrame(ctx, 1440, 1440, 1000000, 12345)
+    step = frame.step
+else:
+    pane = torch.zeros((1440, 1440), dtype=torch.int32, device="cuda")
+    def step():
+        g = ctx.create_map(0, 1000000, 12345, wait=False); c = ctx.create_map(1, 1000000, 12345, wait=False)
+        rp = ctx.params(1440, 1440, 12345); rp.rank = 0; rp.world = world
+        _, st = ctx.render(g, c, rp, d_pane=pane.data_ptr())
+        torch.cuda.synchronize()
+        print("   ", {k: round(getattr(st, k), 3) for k in ("ms_shadow", "ms_gather", "ms_gather_global", "ms_gather_caustic", "ms_group_global", "ms_group_caustic", "ms_total")}, [tuple(round(x, 3) for x in m.times()) for m in (g, c)])
+        g.destroy(); c.destroy()
 for _ in range(3):
-    frame.step()
+    step()
 torch.cuda.synchronize()
 raw = np.zeros(2 * 8192 * 4 + 2 * 16384 * 2, dtype=np.uint32)
 lib.pm_tile_waves(None, 1)
-frame.step(); torch.cuda.synchronize()
+step(); torch.cuda.synchronize()
 lib.pm_tile_waves(raw.ctypes.data_as(ctypes.c_void_p), 0)
 buf = raw[:2 * 8192 * 4].reshape(2, 8192, 4); grp = raw[2 * 8192 * 4:].reshape(2, 16384, 2)
 for kind, name in enumerate(("global", "caustic")):
     a = buf[kind]
-    used = a[:, 0] != 0
+    used = a[:, 2] != 0 if world > 1 else a[:, 0] != 0         # (a small share: only the waves that had a group)
     t0, t1, ng, xcd, blk = a[used, 0].astype(np.int64), a[used, 1].astype(np.int64), a[used, 2], a[used, 3] >> 8, a[used, 3] & 255
     print('   blockIdx & 7 against the XCC_ID register:', [sorted(set(xcd[blk == b].tolist())) for b in range(8)])
     s = t0 - t0.min(); e = t1 - t0.min()      # ticks of the device-wide 100 MHz clock
@@ -41,5 +53,6 @@ for kind, name in enumerate(("global", "caustic")):
     print(f"   {ok.sum()} groups: us per group mean {dur.mean():.0f} p50 {np.median(dur):.0f} p90 {np.percentile(dur, 90):.0f} p99 {np.percentile(dur, 99):.0f} max {dur.max():.0f}; sum {dur.sum() / 1e3:.1f} wave-ms")
     print("   mean us per group by 512 groups of the draw order:", [int(dur[(idx >= b) & (idx < b + 512)].mean()) for b in range(0, int(idx.max()) + 1, 512)])
     print("   mean start (us) by 512 groups:", [int(st[(idx >= b) & (idx < b + 512)].mean()) for b in range(0, int(idx.max()) + 1, 512)])
+    print("   by XCD (blockIdx & 7): groups", [int(ng[blk == b].sum()) for b in range(8)], "last end (us)", [int(e[blk == b].max() / 100) for b in range(8)], "waves with work", [int((ng[blk == b] > 0).sum()) for b in range(8)])
     late = st + dur > 0.85 * (span / 100.0)
     print(f"   groups still running after 85 % of the span: {late.sum()}, their mean duration {dur[late].mean():.0f} us, started at {st[late].mean():.0f} us on average")
