@@ -89,6 +89,7 @@ struct pm_ctx {
     double loose_tiles = 8.0;         // a pixel tile deeper than this many tile spans is not a gather group (PM_LOOSE_TILES; 0: every tile is one)
     bool loose_auto = true;           // ... decided from the frame before: on when many tile groups were handed over as too spread out
     bool loose_on = false;            //     (many small objects), off again when few tiles are that deep; PM_LOOSE_TILES set: always as told
+    bool emit_run = true;             // scenes without a sphere grid: lanes refilled within a wave's run of attempts (PM_EMIT_RUN=0: one attempt per lane, k_emit)
     bool emit_stream = true;          // sphere grid: emission as a stream of attempts per wave (PM_EMIT_STREAM=0: one attempt per lane, for A/B runs)
     int emit_blocks = 384;            // blocks of k_emit_stream per launch: two maps side by side take three quarters of 256 CUs x 4 blocks and leave
                                       // room for the frame's first passes (PM_EMIT_BLOCKS; 320 ... 448: 7.84 ms per step on 10 000 spheres, 512 / 640: 7.95)
@@ -408,6 +409,7 @@ extern "C" int pm_scene_upload(pm_ctx *ctx, const pm_prim *prims, int32_t n) {
     if (const char *e = getenv("PM_SHADOW_PER_RAY")) ctx->shadow_per_ray = e[0] != '0';
     if (const char *e = getenv("PM_SHADOW_QUEUE")) ctx->shadow_queue = e[0] != '0';
     if (const char *e = getenv("PM_EMIT_STREAM")) ctx->emit_stream = e[0] != '0';
+    if (const char *e = getenv("PM_EMIT_RUN")) ctx->emit_run = e[0] != '0';
     if (const char *e = getenv("PM_EMIT_BLOCKS")) { int v = atoi(e); if (v > 0 && v <= 65536) ctx->emit_blocks = v; }
     return PM_OK;
 }
@@ -447,7 +449,9 @@ static int emit_range_on(pm_ctx *ctx, hipStream_t stream, const EmitScratch &es,
         HIPCHK(hipMemsetAsync(next, 0, 4, stream));
         hipLaunchKernelGGL(k_emit_stream, dim3(std::min<uint32_t>(nb, (uint32_t)ctx->emit_blocks)), dim3(256), 0, stream, ctx->gv, kind, K, light, a0, count, es.tmp, es.flag, next);
         hipLaunchKernelGGL(k_flag_counts, dim3(nb), dim3(256), 0, stream, es.flag, count, es.counts);
-    } else
+    } else if (ctx->emit_run)
+        LAUNCH_SCENE_ON(k_emit_run, dim3((uint32_t)((count + 4 * EMIT_RUN - 1) / (4 * EMIT_RUN))), dim3(256), ctx, stream, kind, K, light, a0, count, es.tmp, es.flag, es.counts);
+    else
         LAUNCH_SCENE_ON(k_emit, dim3(nb), dim3(256), ctx, stream, kind, K, light, a0, count, es.tmp, es.flag, es.counts);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, es.counts, es.offs, nb, d_running, bounds_init);
     hipLaunchKernelGGL(k_emit_scatter, dim3(nb), dim3(256), 0, stream, es.tmp, es.flag, es.offs, count, d_out, cap);

@@ -99,6 +99,130 @@ __global__ __launch_bounds__(256) void k_emit(SceneView gs, int map_kind, uint64
     if (threadIdx.x == 0) block_counts[blockIdx.x] = (uint32_t)c;
 }
 
+// The same attempts with refilled lanes (round 3): a photon makes one to four segments (a bounce is taken with the surface's
+// k_d + k_s, the fourth hit stores), so a wave of k_emit runs four rounds of intersections with 47 % of its lanes.  Here a wave
+// owns a run of EMIT_RUN consecutive attempts; a lane whose photon is stored, lost or absorbed waits, and when EMIT_SERVE lanes
+// wait (or none is left tracing) they take the next attempts of the run.  flag[t] / tmp[t] are indexed by the attempt, so
+// the photon order does not depend on which lane traced what; the arithmetic of an attempt is k_emit's, statement by statement.
+#ifndef PM_EMIT_RUN_LEN
+#define PM_EMIT_RUN_LEN 256
+#endif
+#ifndef PM_EMIT_SERVE
+#define PM_EMIT_SERVE 24
+#endif
+constexpr uint32_t EMIT_RUN = PM_EMIT_RUN_LEN;
+static_assert(EMIT_RUN % 256 == 0 && EMIT_RUN <= 1024, "a run is a whole number of the compaction's blocks of 256 attempts");
+template <int MODE>
+__global__ __launch_bounds__(256) void k_emit_run(SceneView gs, int map_kind, uint64_t K, V3 light_color, uint64_t a0, uint64_t count,
+                                                   pm_photon *tmp, uint8_t *flag, uint32_t *block_counts) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    SceneView sv = gs;
+    if (MODE == SCENE_LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
+    const int lane = threadIdx.x & 63;
+    const uint64_t r0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * EMIT_RUN;
+    if (r0 >= count) return;                                   // (wave-uniform, behind the block's only barrier)
+    const uint32_t len = (uint32_t)(count - r0 < EMIT_RUN ? count - r0 : EMIT_RUN);
+    uint32_t next = 0;                                         // attempts of the run handed out so far
+    uint32_t nstored[EMIT_RUN / 256];
+#pragma unroll
+    for (uint32_t b = 0; b < EMIT_RUN / 256; b++) nstored[b] = 0;
+    bool active = false, specular_bounce = false;
+    uint32_t off = 0, j = 0;
+    uint64_t IK = 0;
+    V3 power = light_color, src = {0, 0, 0}, dir = {0, 0, 0};
+    int bounces = 0, exclude = -1;
+    for (;;) {
+        const unsigned long long idle = ~__ballot(active);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (next < len && (n_idle >= (uint32_t)PM_EMIT_SERVE || n_idle == 64u)) {
+            const uint32_t o = next + (uint32_t)lane_rank(idle);
+            if (!active && o < len) {
+                off = o;
+                IK = item_key(K, a0 + r0 + off);
+                j = 0;
+                power = light_color;
+                double x0 = draw(IK, j++) * 2 - 1;
+                double z0 = draw(IK, j++) * 2 + 3;
+                src = {x0, 4.95, z0};
+                double sin_theta = sqrt(draw(IK, j++));
+                double cos_theta = sqrt(1 - sin_theta * sin_theta);
+                double psi = draw(IK, j++) * 6.2831853;
+                double sp, cp;
+                det_sincos(psi, sp, cp);
+                dir = {sin_theta * cp, map_kind == PM_MAP_GLOBAL ? -cos_theta : -2 * cos_theta, sin_theta * sp};
+                normalize(dir);
+                bounces = 0; exclude = -1; specular_bounce = false;
+                active = true;
+            }
+            next = next + n_idle < len ? next + n_idle : len;
+        }
+        if (__ballot(active) == 0ULL) break;                  // nothing in flight and nothing left to hand out
+        bool done = false, stored = false;
+        if (active) {
+            V3 res = {0, 0, 0}, nrm = {0, 0, 0};
+            bounces++;
+            int obj = scene_intersect<MODE>(sv, src, dir, exclude, 0.0, res, nrm);
+            if (obj < 0) done = true;
+            else {
+                double chance = draw(IK, j++);
+                if (bounces > 3) chance = 1;
+                double kd = sv.f(G_DIFFUSE, obj), ks = sv.f(G_SPECULAR, obj), kt = sv.f(G_TRANSMISSION, obj);
+                if (chance < kd + ks) {
+                    V3 n1 = nrm;
+                    double k = n1.x * dir.x + n1.y * dir.y + n1.z * dir.z;
+                    n1.x *= k; n1.y *= k; n1.z *= k;
+                    n1.x *= 2; n1.y *= 2; n1.z *= 2;
+                    src = res;
+                    dir.x = dir.x - n1.x; dir.y = dir.y - n1.y; dir.z = dir.z - n1.z;
+                    normalize(dir);
+                    power.x *= (double)sv.rgb[0 * sv.stride + obj]; power.y *= (double)sv.rgb[1 * sv.stride + obj]; power.z *= (double)sv.rgb[2 * sv.stride + obj];
+                    if (map_kind == PM_MAP_GLOBAL) exclude = obj;
+                    specular_bounce = true;
+                } else if (chance < kd + ks + kt) {
+                    double n = 1 / sv.f(G_REFRACTION, obj);
+                    double d = nrm.x * dir.x + nrm.y * dir.y + nrm.z * dir.z;
+                    V3 n1 = {nrm.x * d, nrm.y * d, nrm.z * d};
+                    n1.x = dir.x - n1.x; n1.y = dir.y - n1.y; n1.z = dir.z - n1.z;
+                    n1.x *= n; n1.y *= n; n1.z *= n;
+                    double s = 1 - (n * n) * (1 - d * d);
+                    double sq = sqrt(s);
+                    V3 n2 = {nrm.x * sq, nrm.y * sq, nrm.z * sq};
+                    n1.x += -n2.x; n1.y += -n2.y; n1.z += -n2.z;
+                    src.x = res.x + n1.x * 0.01; src.y = res.y + n1.y * 0.01; src.z = res.z + n1.z * 0.01;
+                    dir = n1;
+                    normalize(dir);
+                    exclude = -1;
+                    specular_bounce = true;
+                } else {
+                    done = true;
+                    if (!(map_kind == PM_MAP_CAUSTIC && !specular_bounce)) {
+                        pm_photon ph;
+                        ph.x = (float)res.x; ph.y = (float)res.y; ph.z = (float)res.z;
+                        ph.power[0] = (uint8_t)fastfloor(power.x * 0xFF);
+                        ph.power[1] = (uint8_t)fastfloor(power.y * 0xFF);
+                        ph.power[2] = (uint8_t)fastfloor(power.z * 0xFF);
+                        ph.power[3] = 255;
+                        ph.dx = (float)dir.x; ph.dy = (float)dir.y; ph.dz = (float)dir.z;
+                        ph.bounce = (int8_t)bounces;
+                        ph.pad[0] = ph.pad[1] = ph.pad[2] = 0;
+                        tmp[r0 + off] = ph;
+                        stored = true;
+                    }
+                }
+            }
+            if (!done && bounces >= EMIT_MAX_BOUNCES) done = true;
+            if (done) { flag[r0 + off] = stored ? 1 : 0; active = false; }
+        }
+#pragma unroll
+        for (uint32_t b = 0; b < EMIT_RUN / 256; b++) nstored[b] += (uint32_t)__popcll(__ballot(stored && (off >> 8) == b));
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (uint32_t b = 0; b < EMIT_RUN / 256; b++)
+            if (r0 + 256ull * b < count) block_counts[(r0 >> 8) + b] = nstored[b];
+    }
+}
+
 // The same attempts through the sphere grid of a large scene, as a stream (pm_trace.h): a wave keeps 64 attempts in flight.
 // A lane whose photon is absorbed, lost or stored takes the next attempt from the launch's counter while its neighbours go
 // on with theirs; a lane whose photon bounces starts the next segment in place.  Lanes are served in batches (16 waiting, or
