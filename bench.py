@@ -271,7 +271,9 @@ def main():
         # Every kernel class of the step with a device time of its own (HIP events on the stream it runs on), its roofline, and
         # the dominant one: the class with the most device time per step.  The two maps' launches of one kernel template are
         # one class (two launches per step): which of the two is the longer flips from run to run with how they overlap.
-        em_name = "k_emit_stream" if kernel_counters(pmc, "k_emit_stream") or args.scene == "spheres10k" else "k_emit"
+        # (the emission kernel depends on the scene: through a sphere grid k_emit_stream, else k_emit_run; k_emit with PM_EMIT_RUN=0)
+        em_name = ("k_emit_stream" if kernel_counters(pmc, "k_emit_stream") or args.scene == "spheres10k" else
+                   "k_emit" if (pmc and kernel_counters(pmc, "k_emit") and not kernel_counters(pmc, "k_emit_run")) else "k_emit_run")
         pq_name = "k_gather" if (pmc and not kernel_counters(pmc, "k_gather_pair<0>")) else "k_gather_pair"
         n_maps = 2
         left = [st.left_global, st.left_caustic]
@@ -286,7 +288,7 @@ def main():
             "k_shadow_rays": {"launches": 1, "ms": ph["ms_shadow"], "pmc": ("k_shadow_rays",), "tests": tests["shadow"] if tests else None, "what": "shadow any-hit pass, one ray per lane"},
             "k_primary": {"launches": 1, "ms": ph["ms_primary"], "pmc": ("k_primary",), "tests": tests["primary"] if tests else None, "what": "primary closest-hit pass"},
             em_name: {"launches": n_maps, "ms": (map_ms[0][0] + map_ms[1][0]) / args.steps / n_maps, "pmc": (em_name,),
-                      "what": "photon emission of one map (events around k_emit + k_scan_blocks + k_emit_scatter: the first is nearly all of it)"},
+                      "what": "photon emission of one map (events around the emission kernel + k_scan_blocks + k_emit_scatter: the first is nearly all of it)"},
         }
         clock_hz = torch.cuda.get_device_properties(local_rank).clock_rate * 1e3 if hasattr(torch.cuda.get_device_properties(local_rank), "clock_rate") else 2.4e9
 
@@ -342,7 +344,8 @@ def main():
         roof["traffic_note"] = pmc_note
         roof["note"] = (f"dominant kernel class of the step by device time ({roof['ms_per_step']:.3f} ms per step in {roof['launches_per_step']} launch(es), HIP events on the "
                         "stream each launch runs on; kernels of other streams share the device during that time); valu peak = 1024 SIMDs x one FP64 "
-                        f"wave-instruction per 2.2 ns measured (profiles/r03/valu_rates.txt), spec-derived {VALU_SPEC_GINSTR_S:.0f} G/s beside it")
+                        f"wave-instruction per 2.2 ns measured (profiles/r03/valu_rates.txt), spec-derived {VALU_SPEC_GINSTR_S:.0f} G/s beside it; a kernel whose mix is "
+                        "mostly 32-bit integer and move instructions (1.1 ns) can exceed the FP64 figure")
         # the intersection passes against the FP64 peak, whichever kernel dominates (north_star: VALU / occupancy for intersection)
         inter = {r["kernel"]: {"ms": r["ms_per_launch"], "sphere_tests": r.get("sphere_tests"), "plane_tests": r.get("plane_tests"), "tflops": r["achieved"],
                                "frac_of_fp64_peak": r["frac"], "valu_issue_frac": r["valu_issue"]["frac"] if r["valu_issue"] else None,
