@@ -206,8 +206,11 @@ void insert(photon **nearest, double *distances, int k, int size, photon *next, 
 }
 
 int find_nearest_photons(photon **nearest, double *distances, int k, int size, Vec3 *target, kdnode *root, double max_dist) {
-    if (k != PM_K || size != 0 || max_dist != 100) {
-        std::fprintf(stderr, "raytracer_amd: find_nearest_photons supports k = 63, size = 0, max_dist = 100 (the reference's only call pattern)\n");
+    // k = 63 is all the reference's own insert() can do (its sift-down is written out for 31 inner nodes, src/PhotonMap.cpp:142-206),
+    // and a search starts from an empty heap (size = 0).  max_dist is the reference's `dist < max_dist` (:215): any value up to
+    // the 100 the device search is compiled for is served by cutting the ascending result short.
+    if (k != PM_K || size != 0 || !(max_dist > 0) || max_dist > 100) {
+        std::fprintf(stderr, "raytracer_amd: find_nearest_photons supports k = 63, size = 0, 0 < max_dist <= 100 (the reference calls it with 63, 0, 100)\n");
         std::abort();
     }
     if (!root->records && root->count > 0) {
@@ -218,6 +221,7 @@ int find_nearest_photons(photon **nearest, double *distances, int k, int size, V
     double q[3] = {target->x, target->y, target->z};
     int32_t idx[PM_K], found = 0;
     check(pm_knn_query(ctx(), root->map, 1, q, idx, distances, &found), "pm_knn_query");
+    while (found > 0 && !(distances[found - 1] < max_dist)) found--;   // (ascending: what is not below max_dist is a suffix)
     for (int i = 0; i < PM_K; i++) nearest[i] = i < found ? &root->records[idx[i]] : nullptr;
     return found;
 }

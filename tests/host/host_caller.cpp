@@ -6,7 +6,7 @@
 //   host_caller dump <default|caustics|spheres:N:SEED|FILE> <out>   flattened scene records (no GPU needed)
 //   host_caller heap <n> <seed> <out>                               raytrace::insert over a pseudo-random sequence (no GPU)
 //   host_caller trace <w> <h> <out>                                 one un-jittered primary ray per pixel + its mirror bounce
-//   host_caller knn <photons> <seed> <points> <out>                 createPhotonMap + find_nearest_photons on floor points
+//   host_caller knn <photons> <seed> <points> <out> [max_dist]                 createPhotonMap + find_nearest_photons on floor points
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -116,8 +116,9 @@ int main(int argc, char **argv) {
         delete scene;
         return 0;
     }
-    if (mode == "knn" && argc == 6) {
+    if (mode == "knn" && (argc == 6 || argc == 7)) {
         const int n = std::atoi(argv[2]), m = std::atoi(argv[4]);
+        const double max_dist = argc == 7 ? std::atof(argv[6]) : 100;      // the reference's call passes 100 (src/Raytrace.cpp:97)
         randutil::init(std::atoll(argv[3]));
         scheduler::startWorkers(1);
         Scene *scene = defaultScene();
@@ -129,7 +130,7 @@ int main(int argc, char **argv) {
             Vec3 target(-4.0 + 8.0 * q / (m > 1 ? m - 1 : 1), -5.0, 1.0 + 7.0 * ((q * 7) % m) / m);
             photon *nearest[63];
             double distances[63];
-            const int found = find_nearest_photons(nearest, distances, 63, 0, &target, tree, 100);
+            const int found = find_nearest_photons(nearest, distances, 63, 0, &target, tree, max_dist);
             double head[4] = {target.x, target.y, target.z, (double)found};
             std::fwrite(head, 8, 4, f);
             for (int i = 0; i < 63; i++) {

@@ -162,6 +162,29 @@ def test_photon_map_calls_through_the_host_api(caller, tmp_path, orc):
 
 
 @pytest.mark.gpu
+def test_find_nearest_photons_with_a_smaller_max_dist(caller, tmp_path, orc):
+    """max_dist below the reference's 100 (its `dist < max_dist`, src/PhotonMap.cpp:215): the photons closer than that among the
+    exact 63 nearest, in ascending order, and nothing else."""
+    import raytracer_amd as ra
+    n, seed, m, max_dist = 5000, 31337, 40, 0.05
+    out = tmp_path / "knn_md.bin"
+    call(caller, "knn", n, seed, m, out, max_dist)
+    rec = np.fromfile(out, dtype=np.dtype([("q", "<f8", 3), ("found", "<f8"), ("nn", [("d", "<f8"), ("ph", ra.photon_dtype)], 63)]))
+    photons, _ = orc.emit(orc.default_scene(), 0, seed, n)
+    omap = orc.Map(photons)
+    cut = 0
+    for row in rec:
+        found, idx, d2 = omap.knn_exact(row["q"])
+        want = int(np.count_nonzero(d2[:found] < max_dist))
+        assert int(row["found"]) == want
+        assert np.array_equal(row["nn"]["d"][:want].view(np.uint64), d2[:want].view(np.uint64))
+        assert row["nn"]["ph"][:want].tobytes() == photons[idx[:want]].tobytes()
+        cut += want < found
+    omap.close()
+    assert 0 < cut        # the test means something: some searches were cut short
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("scene,samples", [("mixed100", 1), ("caustics", 3)])
 def test_cli_renders_a_scene_file(tmp_path, orc, scene, samples):
     """raytracer --scene FILE: the PNG equals the oracle's pane of that scene through the front-end (box filter, flip, byte order)."""
