@@ -78,6 +78,9 @@ struct pm_ctx {
     hipStream_t aux = nullptr;           // the caustic gather runs beside the global one
     hipStream_t aux2 = nullptr;          // and the per-query gather of the bounced pixels' shade points beside both
     hipEvent_t ev_join2 = nullptr;
+    hipStream_t sp_stream = nullptr;     // the ordering of the bounced pixels' shade points, beside the shadow pass (PM_SP_STREAM=0: behind it, on the caller's stream)
+    hipEvent_t ev_sec = nullptr, ev_sp = nullptr;
+    bool sp_on_side = true;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_g[2][3] = {};          // per map: gather begins, group kernel done, per-query kernel done
     hipEvent_t ev_part[2][4] = {};       // per map: a part of the group launches is done (its leftovers may be gathered)
@@ -162,6 +165,10 @@ static int ctx_init(pm_ctx *ctx) {
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_frame, hipEventDisableTiming));
     ctx->debug = getenv("PM_DEBUG") != nullptr;      // (the environment is read here, once, not per frame)
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming));
+    HIPCHK(hipStreamCreateWithFlags(&ctx->sp_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_sec, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_sp, hipEventDisableTiming));
+    if (const char *e = getenv("PM_SP_STREAM")) ctx->sp_on_side = e[0] != '0';
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     for (int k = 0; k < 2; k++) for (int i = 0; i < 3; i++) HIPCHK(hipEventCreate(&ctx->ev_g[k][i]));
@@ -209,6 +216,9 @@ extern "C" int pm_ctx_destroy(pm_ctx *ctx) {
     if (ctx->h_u64) (void)hipHostFree(ctx->h_u64);
     for (int i = 0; i < N_EVENTS; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
+    if (ctx->sp_stream) { (void)hipStreamSynchronize(ctx->sp_stream); (void)hipStreamDestroy(ctx->sp_stream); }
+    if (ctx->ev_sec) (void)hipEventDestroy(ctx->ev_sec);
+    if (ctx->ev_sp) (void)hipEventDestroy(ctx->ev_sp);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     for (int k = 0; k < 2; k++) for (int i = 0; i < 3; i++) if (ctx->ev_g[k][i]) (void)hipEventDestroy(ctx->ev_g[k][i]);
@@ -221,6 +231,7 @@ extern "C" int pm_ctx_synchronize(pm_ctx *ctx) {
     if (!ctx) return fail(PM_EINVAL, "ctx is NULL");
     PMCHK(set_device(ctx));
     for (int i = 0; i < 2; i++) if (ctx->slot[i].stream) HIPCHK(hipStreamSynchronize(ctx->slot[i].stream));
+    if (ctx->sp_stream) HIPCHK(hipStreamSynchronize(ctx->sp_stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return PM_OK;
 }
@@ -1084,6 +1095,7 @@ extern "C" int pm_render(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
         const std::string msg = g_err;
         (void)hipSetDevice(ctx->device);
         for (int i = 0; i < 2; i++) if (ctx->slot[i].stream) (void)hipStreamSynchronize(ctx->slot[i].stream);
+        if (ctx->sp_stream) (void)hipStreamSynchronize(ctx->sp_stream);
         (void)hipStreamSynchronize(ctx->stream);
         g_err = msg;
     }
@@ -1120,6 +1132,37 @@ static int enqueue_frame(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
     LAUNCH_SCENE(k_secondary, dim3(std::min<unsigned>((c_cap + 255) / 256, 4096u)), block, ctx, fp, d_ctr, q, ctx->clist.as<uint32_t>(), c_cap, tab);
     hipLaunchKernelGGL(k_mark_secondary, dim3(1), dim3(64), 0, ctx->stream, d_ctr, q.cap, b_cap);
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+    // The shade points of bounced pixels (slots n_sp0 .. n_sp0 + n_bounced) in spatial order, for the group kernel: a chain of
+    // thirteen small launches that needs the bounce pass and nothing else.  It runs beside the shadow pass on a stream of its own
+    // (round 3; PM_SP_STREAM=0: behind the shadow pass on the caller's stream) and beside the maps' builds.
+    auto queue_sp_order = [&](hipStream_t sps) -> int {
+        HIPCHK(hipMemsetAsync(ctx->sp_bounds.p, 0xFF, 12, sps));                                   // minima
+        HIPCHK(hipMemsetAsync(ctx->sp_bounds.as<unsigned char>() + 12, 0, 12, sps));             // maxima
+        hipLaunchKernelGGL(k_sp_bounds, dim3(std::min(256u, (b_cap + 255) / 256)), block, 0, sps, q, d_ctr, ctx->sp_loose.as<uint32_t>(), ctx->sp_bounds.as<uint32_t>());
+        hipLaunchKernelGGL(k_sp_morton, dim3((b_cap + 255) / 256), block, 0, sps, q, d_ctr, ctx->sp_loose.as<uint32_t>(), ctx->sp_bounds.as<uint32_t>(),
+                           ctx->sp_keys_in.as<uint64_t>(), ctx->sp_vals_in.as<uint32_t>());
+        HIPCHK(radix_sort_pairs_30(sps, ctx->sp_keys_in.as<uint64_t>(), ctx->sp_vals_in.as<uint32_t>(), ctx->sp_keys_out.as<uint64_t>(),
+                                   ctx->sp_vals_out.as<uint32_t>(), ctx->sp_sort_tmp.as<uint32_t>(), b_cap, &d_ctr->n_sorted));
+        // cells of about six 63-NN radii (measured best on the default scene; most runs are then left to the tile kernel's own
+        // test of how far a group is spread): r^2 = 63 / (pi * density), density = photons / surface, surface taken as that
+        // of a cube over the points' extent (the sparser of the two maps decides)
+        long long n_ph = std::max<long long>(1, std::min(gmap ? gmap->n : (1LL << 40), cmap ? cmap->n : (1LL << 40)));
+        double cell_rel = ctx->sp_cell * sqrt(63.0 * 6.0 / (3.14159265 * (double)n_ph));
+        hipLaunchKernelGGL(k_sp_pieces, dim3((b_cap + 255) / 256), block, 0, sps, ctx->sp_keys_out.as<uint64_t>(), cell_rel, ctx->sp_pieces.as<uint2>(), d_ctr);
+        // one wave per piece (a scene of many small objects has more surface than the cube over its points, which the estimate
+        // of the photon density assumes: twice the expected set is allowed there; measured 8.55 -> 8.3 ms on 10 000 spheres)
+        hipLaunchKernelGGL(k_sp_classify, dim3(std::min<unsigned>((b_cap + 3) / 4, 1024u)), block, 0, sps, q, ctx->sp_vals_out.as<uint32_t>(), ctx->sp_pieces.as<uint2>(),
+                           ctx->sp_bounds.as<uint32_t>(), (double)n_ph / 6.0, ctx->sp_est * (loose_k > 0 && ctx->loose_auto ? 2.0 : 1.0) * (double)PM_TILE_EST_MAX, (uint32_t)ctx->sp_min_run,
+                           ctx->sp_groups.as<uint2>(), d_ctr, ctx->sp_early.as<uint32_t>());
+        HIPCHK(hipGetLastError());
+        return PM_OK;
+    };
+    if (sort_bounced && ctx->sp_on_side) {
+        HIPCHK(hipEventRecord(ctx->ev_sec, ctx->stream));
+        HIPCHK(hipStreamWaitEvent(ctx->sp_stream, ctx->ev_sec, 0));
+        PMCHK(queue_sp_order(ctx->sp_stream));
+        HIPCHK(hipEventRecord(ctx->ev_sp, ctx->sp_stream));
+    }
     // one lane per shadow ray; or (A/B switch) one lane per shade point with its 25 rays in sequence
     const dim3 grid_sh(std::min<unsigned>((q.cap + 9) / 10, 4 * cus8));
     if (count_tests && ctx->shadow_queue) LAUNCH_SCENE(k_shadow_rays_count, grid_sh, block, ctx, fp, q, d_ctr);
@@ -1138,28 +1181,9 @@ static int enqueue_frame(pm_ctx *ctx, pm_map *gmap, pm_map *cmap, const pm_rende
     uint32_t *left = ctx->left.as<uint32_t>();
     const bool use_tiles = ctx->use_tiles;
     const int dbg = ctx->debug ? 1 : 0;
-    // The shade points of bounced pixels (slots n_sp0 .. n_sp0 + n_bounced) in spatial order, for the group kernel; queued
-    // before the wait for the maps, whose builds this overlaps.
     if (sort_bounced) {
-        HIPCHK(hipMemsetAsync(ctx->sp_bounds.p, 0xFF, 12, ctx->stream));                                   // minima
-        HIPCHK(hipMemsetAsync(ctx->sp_bounds.as<unsigned char>() + 12, 0, 12, ctx->stream));             // maxima
-        hipLaunchKernelGGL(k_sp_bounds, dim3(std::min(256u, (b_cap + 255) / 256)), block, 0, ctx->stream, q, d_ctr, ctx->sp_loose.as<uint32_t>(), ctx->sp_bounds.as<uint32_t>());
-        hipLaunchKernelGGL(k_sp_morton, dim3((b_cap + 255) / 256), block, 0, ctx->stream, q, d_ctr, ctx->sp_loose.as<uint32_t>(), ctx->sp_bounds.as<uint32_t>(),
-                           ctx->sp_keys_in.as<uint64_t>(), ctx->sp_vals_in.as<uint32_t>());
-        HIPCHK(radix_sort_pairs_30(ctx->stream, ctx->sp_keys_in.as<uint64_t>(), ctx->sp_vals_in.as<uint32_t>(), ctx->sp_keys_out.as<uint64_t>(),
-                                   ctx->sp_vals_out.as<uint32_t>(), ctx->sp_sort_tmp.as<uint32_t>(), b_cap, &d_ctr->n_sorted));
-        // cells of about six 63-NN radii (measured best on the default scene; most runs are then left to the tile kernel's own
-        // test of how far a group is spread): r^2 = 63 / (pi * density), density = photons / surface, surface taken as that
-        // of a cube over the points' extent (the sparser of the two maps decides)
-        long long n_ph = std::max<long long>(1, std::min(gmap ? gmap->n : (1LL << 40), cmap ? cmap->n : (1LL << 40)));
-        double cell_rel = ctx->sp_cell * sqrt(63.0 * 6.0 / (3.14159265 * (double)n_ph));
-        hipLaunchKernelGGL(k_sp_pieces, dim3((b_cap + 255) / 256), block, 0, ctx->stream, ctx->sp_keys_out.as<uint64_t>(), cell_rel, ctx->sp_pieces.as<uint2>(), d_ctr);
-        // one wave per piece (a scene of many small objects has more surface than the cube over its points, which the estimate
-        // of the photon density assumes: twice the expected set is allowed there; measured 8.55 -> 8.3 ms on 10 000 spheres)
-        hipLaunchKernelGGL(k_sp_classify, dim3(std::min<unsigned>((b_cap + 3) / 4, 1024u)), block, 0, ctx->stream, q, ctx->sp_vals_out.as<uint32_t>(), ctx->sp_pieces.as<uint2>(),
-                           ctx->sp_bounds.as<uint32_t>(), (double)n_ph / 6.0, ctx->sp_est * (loose_k > 0 && ctx->loose_auto ? 2.0 : 1.0) * (double)PM_TILE_EST_MAX, (uint32_t)ctx->sp_min_run,
-                           ctx->sp_groups.as<uint2>(), d_ctr, ctx->sp_early.as<uint32_t>());
-        HIPCHK(hipGetLastError());
+        if (ctx->sp_on_side) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sp, 0));     // (queued beside the shadow pass, above)
+        else PMCHK(queue_sp_order(ctx->stream));
     }
     const uint32_t *sorted = ctx->sp_vals_out.as<uint32_t>();
     // what the group kernel does not take is the per-query kernel's range: everything without the group kernel, the
