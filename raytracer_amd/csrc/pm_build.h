@@ -101,28 +101,32 @@ __global__ __launch_bounds__(256) void k_emit(SceneView gs, int map_kind, uint64
 
 // The same attempts with refilled lanes (round 3): a photon makes one to four segments (a bounce is taken with the surface's
 // k_d + k_s, the fourth hit stores), so a wave of k_emit runs four rounds of intersections with 47 % of its lanes.  Here a wave
-// owns a run of EMIT_RUN consecutive attempts; a lane whose photon is stored, lost or absorbed waits, and when EMIT_SERVE lanes
-// wait (or none is left tracing) they take the next attempts of the run.  flag[t] / tmp[t] are indexed by the attempt, so
+// owns a run of EMIT_RUN consecutive attempts; a lane whose photon is stored, lost or absorbed takes the next attempt of the run in
+// the same round.  The first rays of the attempts are set up 64 at a time by the whole wave (the set-up is a third of an
+// attempt's instructions: done for the few lanes that fall idle in a round it would cost as much as for 64) and wait in LDS.  flag[t] / tmp[t] are indexed by the attempt, so
 // the photon order does not depend on which lane traced what; the arithmetic of an attempt is k_emit's, statement by statement.
 #ifndef PM_EMIT_RUN_LEN
 #define PM_EMIT_RUN_LEN 256
 #endif
-#ifndef PM_EMIT_SERVE
-#define PM_EMIT_SERVE 24
-#endif
 constexpr uint32_t EMIT_RUN = PM_EMIT_RUN_LEN;
 static_assert(EMIT_RUN % 256 == 0 && EMIT_RUN <= 1024, "a run is a whole number of the compaction's blocks of 256 attempts");
+// LDS of one wave: the first rays of up to 64 attempts, set up by the whole wave at once (one attempt per lane) and handed to
+// lanes as they fall idle.  [field][entry]: x0, z0, dir x y z, and the attempt's key.
+struct EmitPool { double f[5][64]; uint64_t ik[64]; };
 template <int MODE>
 __global__ __launch_bounds__(256) void k_emit_run(SceneView gs, int map_kind, uint64_t K, V3 light_color, uint64_t a0, uint64_t count,
                                                    pm_photon *tmp, uint8_t *flag, uint32_t *block_counts) {
     extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ EmitPool pools[4];
     SceneView sv = gs;
     if (MODE == SCENE_LDS) { sv = stage_scene(gs, smem); __syncthreads(); }
     const int lane = threadIdx.x & 63;
+    EmitPool &pool = pools[threadIdx.x >> 6];
     const uint64_t r0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * EMIT_RUN;
     if (r0 >= count) return;                                   // (wave-uniform, behind the block's only barrier)
     const uint32_t len = (uint32_t)(count - r0 < EMIT_RUN ? count - r0 : EMIT_RUN);
-    uint32_t next = 0;                                         // attempts of the run handed out so far
+    uint32_t next = 0;                                         // attempts of the run set up so far
+    uint32_t pool_base = 0, pool_n = 0, pool_at = 0;           // the pool holds attempts pool_base .. pool_base + pool_n, pool_at of them handed out
     uint32_t nstored[EMIT_RUN / 256];
 #pragma unroll
     for (uint32_t b = 0; b < EMIT_RUN / 256; b++) nstored[b] = 0;
@@ -134,29 +138,49 @@ __global__ __launch_bounds__(256) void k_emit_run(SceneView gs, int map_kind, ui
     for (;;) {
         const unsigned long long idle = ~__ballot(active);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
-        if (next < len && (n_idle >= (uint32_t)PM_EMIT_SERVE || n_idle == 64u)) {
-            const uint32_t o = next + (uint32_t)lane_rank(idle);
-            if (!active && o < len) {
-                off = o;
-                IK = item_key(K, a0 + r0 + off);
-                j = 0;
+        if (n_idle != 0u && (pool_at < pool_n || next < len)) {
+            if (pool_at == pool_n) {
+                // the pool is empty: the next 64 attempts of the run are set up, one per lane (src/PhotonMap.cpp:290-301, :402-413)
+                wave_lds_fence();
+                const uint32_t o = next + (uint32_t)lane;
+                if (o < len) {
+                    const uint64_t ik = item_key(K, a0 + r0 + o);
+                    uint32_t jj = 0;
+                    double x0 = draw(ik, jj++) * 2 - 1;
+                    double z0 = draw(ik, jj++) * 2 + 3;
+                    double sin_theta = sqrt(draw(ik, jj++));
+                    double cos_theta = sqrt(1 - sin_theta * sin_theta);
+                    double psi = draw(ik, jj++) * 6.2831853;
+                    double sp, cp;
+                    det_sincos(psi, sp, cp);
+                    V3 d0 = {sin_theta * cp, map_kind == PM_MAP_GLOBAL ? -cos_theta : -2 * cos_theta, sin_theta * sp};
+                    normalize(d0);
+                    pool.f[0][lane] = x0; pool.f[1][lane] = z0; pool.f[2][lane] = d0.x; pool.f[3][lane] = d0.y; pool.f[4][lane] = d0.z;
+                    pool.ik[lane] = ik;
+                }
+                pool_base = next;
+                pool_n = len - next < 64u ? len - next : 64u;
+                pool_at = 0;
+                next += pool_n;
+                wave_lds_fence();
+            }
+            const uint32_t e = pool_at + (uint32_t)lane_rank(idle);
+            if (!active && e < pool_n) {
+                off = pool_base + e;
+                IK = pool.ik[e];
+                j = 4;
                 power = light_color;
-                double x0 = draw(IK, j++) * 2 - 1;
-                double z0 = draw(IK, j++) * 2 + 3;
-                src = {x0, 4.95, z0};
-                double sin_theta = sqrt(draw(IK, j++));
-                double cos_theta = sqrt(1 - sin_theta * sin_theta);
-                double psi = draw(IK, j++) * 6.2831853;
-                double sp, cp;
-                det_sincos(psi, sp, cp);
-                dir = {sin_theta * cp, map_kind == PM_MAP_GLOBAL ? -cos_theta : -2 * cos_theta, sin_theta * sp};
-                normalize(dir);
+                src = {pool.f[0][e], 4.95, pool.f[1][e]};
+                dir = {pool.f[2][e], pool.f[3][e], pool.f[4][e]};
                 bounces = 0; exclude = -1; specular_bounce = false;
                 active = true;
             }
-            next = next + n_idle < len ? next + n_idle : len;
+            pool_at = pool_at + n_idle < pool_n ? pool_at + n_idle : pool_n;
         }
-        if (__ballot(active) == 0ULL) break;                  // nothing in flight and nothing left to hand out
+        if (__ballot(active) == 0ULL) {
+            if (pool_at == pool_n && next >= len) break;      // nothing in flight, nothing left to hand out
+            continue;                                         // (the pool ran dry half way through a hand-out: it is filled next)
+        }
         bool done = false, stored = false;
         if (active) {
             V3 res = {0, 0, 0}, nrm = {0, 0, 0};
