@@ -5,6 +5,7 @@ must give the same bits; a map whose emission and build are left on a build stre
 waiting call produces; an emission range that falls short of n photons must be repaired.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -61,6 +62,35 @@ def test_async_map_creation_is_the_same_map(gpu_ctx):
         assert np.array_equal(ma.download().view(np.uint8), mb.download().view(np.uint8))
     for m in a + b:
         m.destroy()
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_ragged_attempt_ranges_and_both_emission_kernels(orc, kind):
+    """pm_emit_range on ranges that end in the middle of a wave, of a run of 256 attempts and of a block of 1 024: the
+    stored photons are the oracle's for exactly those attempts, whichever kernel emits them (lanes refilled from a wave's run
+    of attempts: the default; one attempt per lane: PM_EMIT_RUN=0, read when the scene is uploaded)."""
+    import torch
+    import raytracer_amd as ra
+    seed, lc = 77, (0.6, 0.6, 0.6)
+    scene = orc.default_scene()
+    kept = {}
+    for env in ("1", "0"):
+        os.environ["PM_EMIT_RUN"] = env
+        ctx = ra.Context(0)
+        try:
+            ctx.upload_scene(ra.default_scene())
+            for begin, count in ((0, 1), (5, 63), (1000, 64), (123, 65), (0, 255), (9, 257), (4096, 1023), (77, 1025), (31, 5000)):
+                out = torch.zeros((count, 8), dtype=torch.int32, device="cuda")
+                got = ctx.emit_range(kind, seed, lc, begin, count, out.data_ptr(), count)
+                rec = out.cpu().numpy()[:got].copy().view(ra.photon_dtype).reshape(-1)
+                want = [ph for ok, ph, _ in (orc.emit_attempt(scene, kind, seed, a) for a in range(begin, begin + count)) if ok]
+                assert got == len(want), (env, begin, count)
+                assert rec.tobytes() == (np.array(want, dtype=ra.photon_dtype).tobytes() if want else b""), (env, begin, count)
+                if env == "1": kept[(begin, count)] = rec.tobytes()
+                else: assert kept[(begin, count)] == rec.tobytes()
+        finally:
+            ctx.close()
+            os.environ.pop("PM_EMIT_RUN", None)
 
 
 def test_emission_shortfall_is_repaired():
