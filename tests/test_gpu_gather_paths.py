@@ -41,6 +41,23 @@ def test_group_gather_matches_per_query_gather(monkeypatch):
     assert (st_t.gathers, st_t.shadow_queries) == (st_q.gathers, st_q.shadow_queries)
 
 
+def test_ordering_of_bounced_points_beside_or_behind_the_shadow_pass(monkeypatch, orc):
+    """The bounced pixels' shade points are put in spatial order on a stream of their own beside the shadow pass (the default)
+    or behind it on the caller's stream (PM_SP_STREAM=0, read when the context is created): the same pane, and the oracle's."""
+    w, h, n, seed = 400, 260, 60000, 99
+    monkeypatch.setenv("PM_SP_STREAM", "1")
+    pane_side, st_side = _render(monkeypatch, True, w, h, n, seed)
+    monkeypatch.setenv("PM_SP_STREAM", "0")
+    pane_behind, st_behind = _render(monkeypatch, True, w, h, n, seed)
+    assert np.array_equal(pane_side, pane_behind)
+    assert (st_side.gathers, st_side.grouped_global, st_side.grouped_caustic) == (st_behind.gathers, st_behind.grouped_global, st_behind.grouped_caustic)
+    scene = orc.default_scene()
+    og, oc = orc.Map(orc.emit(scene, 0, seed, n)[0]), orc.Map(orc.emit(scene, 1, seed, n)[0])
+    want, _ = orc.render(scene, og, oc, orc.params(w, h, seed), nthreads=16)
+    og.close(); oc.close()
+    assert np.array_equal(pane_side, want)
+
+
 @pytest.mark.parametrize("n", [40, 3000])
 def test_group_gather_sparse_maps(monkeypatch, n):
     """Maps so sparse that groups are handed over (fewer than 63 photons, radius beyond MAX_R2, huge spread)."""
