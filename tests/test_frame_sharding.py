@@ -95,7 +95,14 @@ def _worker(rank, world, port, w, h, n, seed, q):
     marks = np.zeros((h, w), dtype=np.uint32)
     for b in frame.owned_row_blocks(h, rank, world):
         marks[b * 16:min(h, b * 16 + 16)] = _row_marks(h, w)[b * 16:min(h, b * 16 + 16)]
-    full_marks = frame.gather_row_blocks(dist, torch.from_numpy(marks.view(np.int32)), rank, world)
+    # through the cached staging buffers GpuFrame uses (whole row blocks only: the other heights take the plain path), twice: the
+    # second frame reuses the first one's buffers
+    cache = {}
+    first = frame.gather_row_blocks(dist, torch.from_numpy((marks ^ np.uint32(0x5A5A)).view(np.int32)), rank, world, cache)
+    if rank == 0:
+        assert np.array_equal(first.numpy().view(np.uint32), _row_marks(h, w) ^ np.uint32(0x5A5A))
+    full_marks = frame.gather_row_blocks(dist, torch.from_numpy(marks.view(np.int32)), rank, world, cache)
+    assert (len(cache) == 1) == (h % 16 == 0)
     if rank == 0:
         q.put((maps[0].tobytes(), maps[1].tobytes(), full.numpy().view(np.uint32).copy(), full_marks.numpy().view(np.uint32).copy()))
     dist.barrier()
