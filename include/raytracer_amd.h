@@ -106,7 +106,7 @@ typedef struct pm_stats {
 int pm_ctx_create(int device, pm_ctx **out);
 int pm_ctx_destroy(pm_ctx *ctx);
 /* scheduler::waitForCompletion(), src/JobSystem.cpp:109-118: returns when everything the context has queued (the caller's
- * stream and the library's two build / gather streams) is done.  Unlike the reference's, the context stays usable. */
+ * stream and the library's own three: two for builds and gathers, one for the ordering of bounced shade points) is done.  Unlike the reference's, the context stays usable. */
 int pm_ctx_synchronize(pm_ctx *ctx);
 /* Switches of a context that are no part of the reference's interface (it reads nothing at run time: its tunables are
  * #defines, src/Raytrace.cpp:11-27).  "debug" (0 / 1): per-frame statistics on stderr; starts as 1 when PM_DEBUG is in the
